@@ -1,0 +1,156 @@
+/* schnorr_sig_amd.h -- C ABI of the MI355X-native batched Schnorr verification engine.
+ *
+ * Drop-in boundary for the verification path of toposware/schnorr-sig.  The reference has
+ * no FFI (`#![deny(unsafe_code)]`, src/lib.rs:152); these entry points are what a Rust
+ * `-sys` shim would bind to replace, one for one:
+ *
+ *   ssa_verify              <- Signature::verify            src/signature.rs:181-205
+ *                              (KeyPair::verify_signature   src/signature.rs:159-165,
+ *                               PublicKey::verify_signature src/signature.rs:170-176,
+ *                               KeyedSignature::verify      src/signature.rs:232-234)
+ *   ssa_verify_batch        <- verify_batch                 src/batch.rs:31-50
+ *   ssa_verify_many         <- n x Signature::verify (the per-signature accept/reject vector
+ *                              BASELINE.json's north_star asks for)
+ *   ssa_hash_message_many   <- hash_message                 src/signature.rs:274-306
+ *   ssa_rescue_hash_many    <- RescueHash::hash_field       src/signature.rs:303
+ *   ssa_keygen_sign_many    <- KeyPair::new / KeyPair::sign src/keypair.rs:57-65,
+ *                                                           src/signature.rs:114-129
+ *   status codes            <- SignatureError               src/error.rs:13-18
+ *   record sizes            <- src/constants.rs:12-30
+ *
+ * Data layout (all little-endian, canonical limbs -- pinned by the reference's fixtures,
+ * src/signature.rs:387-404, :430-460):
+ *   signature  81 B = R.x c0..c5 (6 x u64) | flag byte (ignored by verify, src/signature.rs:186)
+ *                     | e (32 B, < q)
+ *   public key 96 B = affine x c0..c5 | y c0..c5   (PublicKey.0 is an AffinePoint in memory,
+ *                     src/public.rs:24; the 49-B compressed form needs an Fp6 sqrt and is a
+ *                     "next" row)
+ *   messages   either a dense array with a fixed stride, or concatenated bytes + (n+1) offsets
+ *
+ * Ownership: the caller owns every buffer for the duration of the call; the library keeps
+ * no pointer.  A context owns its device memory and one HIP stream; calls on one context
+ * must be serialised by the caller, several contexts may be used concurrently.
+ * No entry point aborts: inputs on which the reference would panic (non-canonical limbs,
+ * src/signature.rs:186; e >= q) get status SSA_MALFORMED.
+ */
+#ifndef SCHNORR_SIG_AMD_H
+#define SCHNORR_SIG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSA_SIGNATURE_LENGTH 81   /* src/constants.rs:27 */
+#define SSA_AFFINE_PK_LENGTH 96   /* 2 x BASEFIELD_LENGTH, src/constants.rs:18 */
+#define SSA_SCALAR_LENGTH 32      /* src/constants.rs:12 */
+#define SSA_DIGEST_LENGTH 32      /* hash_message output, src/signature.rs:274 */
+#define SSA_PARAMS_LENGTH 2816
+
+/* per-signature status (src/error.rs:13-18) */
+#define SSA_OK 0
+#define SSA_INVALID_PUBLIC_KEY 1  /* SignatureError::InvalidPublicKey */
+#define SSA_INVALID_SIGNATURE 2   /* SignatureError::InvalidSignature */
+#define SSA_MALFORMED 3           /* the reference would panic on this input */
+
+/* API return codes (negative = the call itself failed) */
+#define SSA_ERR_ARG (-1)
+#define SSA_ERR_HIP (-2)
+#define SSA_ERR_PARAMS (-3)
+#define SSA_ERR_NO_DEVICE (-4)
+
+/* flags */
+#define SSA_FLAG_CHECK_TORSION 1u /* Signature::verify semantics (src/signature.rs:182-184);
+                                     off = verify_batch semantics (src/batch.rs has no check) */
+
+typedef struct ssa_ctx ssa_ctx;
+
+/* Parameter blob (Rescue-Prime instance + generator), see schnorr-sig_amd/params/gen_params.py.
+ *   char magic[8] = "SSAPARM1"; u32 n_rounds, rate_off; i32 cap_len_idx; u32 pad_mode,
+ *   digest_off, flags; u64 mds[144]; u64 ark1[8][12]; u64 ark2[8][12]; u64 gen_x[6], gen_y[6]
+ * params == NULL selects the built-in default blob. */
+int ssa_ctx_create(ssa_ctx **out, int device, const void *params, size_t params_len);
+void ssa_ctx_destroy(ssa_ctx *ctx);
+const char *ssa_strerror(int rc);
+/* the built-in blob (SSA_PARAMS_LENGTH bytes) */
+const void *ssa_default_params(void);
+/* make the context issue its work on an existing hipStream_t (NULL = its own stream) */
+int ssa_ctx_set_stream(ssa_ctx *ctx, void *hip_stream);
+/* average duration (ms) of the `ssa_k_verify` launches since the last call, measured with
+ * hipEvents on the context's stream when profiling is on; resets the statistics. */
+int ssa_ctx_enable_timing(ssa_ctx *ctx, int on);
+int ssa_ctx_read_timing(ssa_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
+
+/* ---- host-buffer entry points (what the Rust shim binds) ----------------------------- */
+
+/* Signature::verify for one signature.  Returns a status code. */
+int ssa_verify(ssa_ctx *ctx, const uint8_t sig[SSA_SIGNATURE_LENGTH],
+               const uint8_t pk[SSA_AFFINE_PK_LENGTH], const uint8_t *msg, size_t msg_len,
+               uint32_t flags);
+
+/* n independent verifications; status_out[i] in {0,1,2,3}; *n_fail_out = #(status != 0).
+ * msg_off != NULL: message i = msgs[msg_off[i] .. msg_off[i+1]);
+ * msg_off == NULL: message i = msgs[i*msg_stride .. i*msg_stride + msg_len).
+ * pk_inf (optional, n bytes): non-zero marks pk i as the identity. */
+int ssa_verify_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                    const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
+                    size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,
+                    uint64_t *n_fail_out);
+
+/* verify_batch: one verdict for the batch = AND of the per-signature verdicts (equal to the
+ * reference's MSM verdict on honest and on corrupted-but-well-formed inputs; divergence
+ * classes are listed in DESIGN.md).  Returns SSA_OK, SSA_INVALID_SIGNATURE (or
+ * SSA_INVALID_PUBLIC_KEY with SSA_FLAG_CHECK_TORSION, SSA_MALFORMED) -- the smallest
+ * non-zero status present.  n == 0 returns SSA_OK like the reference. */
+int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
+                     const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                     uint32_t flags);
+
+/* hash_message for n (R.x, pk, message) triples -> n x 32-byte digests */
+int ssa_hash_message_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks,
+                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
+                          size_t msg_len, size_t n, uint8_t *digests_out);
+
+/* Rescue-Prime hash_field over n rows of `felts_per_row` canonical u64 -> n x 4 felts */
+int ssa_rescue_hash_many(ssa_ctx *ctx, const uint64_t *felts, uint32_t felts_per_row, size_t n,
+                         uint64_t *digests_out);
+
+/* pk_i = [sk_i]G (affine, 96 B) and sig_i = sign(sk_i, nonce_i, msg_i).  Scalars are 32-byte
+ * LE values reduced mod q; sk == 0 is rejected with SSA_ERR_ARG like PrivateKey::new
+ * (src/private.rs:49-57). */
+int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces,
+                         const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
+                         size_t msg_len, size_t n, uint8_t *pks_out, uint8_t *sigs_out);
+
+/* ---- device-buffer entry points: same semantics, every pointer is a device pointer ----
+ * (work is enqueued on the context's stream; outputs are valid after ssa_ctx_sync) */
+int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
+                           const uint8_t *d_pk_inf, const uint8_t *d_msgs,
+                           const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                           uint32_t flags, uint8_t *d_status_out, uint64_t *d_n_fail_out);
+int ssa_hash_message_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
+                                 const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                 size_t msg_stride, size_t msg_len, size_t n,
+                                 uint8_t *d_digests_out);
+int ssa_rescue_hash_many_device(ssa_ctx *ctx, const uint64_t *d_felts, uint32_t felts_per_row,
+                                size_t n, uint64_t *d_digests_out);
+int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces,
+                                const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                size_t msg_stride, size_t msg_len, size_t n, uint8_t *d_pks_out,
+                                uint8_t *d_sigs_out);
+int ssa_ctx_sync(ssa_ctx *ctx);
+
+/* ---- arithmetic probes (unit parity with the oracle; not part of the reference API) --- */
+/* op: 0 = Fp6 mul, 1 = Fp6 sqr, 2 = Fp6 inv, 3 = point add (affine 12+12 -> 12 felts + inf),
+ *     4 = scalar mul [k]P (k in a[0..4], P in b), 5 = Fp mul (a[0]*b[0]), 6 = Fp inv */
+int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
+                    size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride);
+/* register-resident Fp-mul throughput probe: returns Fp multiplications per second */
+int ssa_bench_fpmul(ssa_ctx *ctx, int variant, double *fpmul_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCHNORR_SIG_AMD_H */

@@ -1,0 +1,409 @@
+"""schnorr_sig_amd -- host-side mirror of toposware/schnorr-sig's verification API over the
+MI355X-native HIP engine (C ABI: include/schnorr_sig_amd.h).
+
+This package is plumbing only: it loads csrc/libschnorr_sig_amd.so with ctypes and forwards
+to it.  There is no CPU compute path; if the HIP library is missing, import fails loudly.
+
+Reference API mirrored (names and semantics, reference file:line):
+  Signature.verify(message, pkey)            src/signature.rs:181-205
+  PublicKey.verify_signature / KeyPair.verify_signature   src/signature.rs:159-176
+  KeyPair.new / KeyPair.sign                 src/keypair.rs:57-65, src/signature.rs:114-129
+  verify_batch(signatures, public_keys, messages, rng)    src/batch.rs:31-50
+  SignatureError.{InvalidPublicKey, InvalidSignature}     src/error.rs:13-31
+  *_LENGTH constants                         src/constants.rs:12-30
+
+The directory is named `schnorr-sig_amd`; import it as `schnorr_sig_amd` (repo-root shim).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libschnorr_sig_amd.so")
+
+# src/constants.rs:12-30
+SCALAR_LENGTH = 32
+PRIVATE_KEY_LENGTH = 32
+BASEFIELD_LENGTH = 48
+PUBLIC_KEY_LENGTH = 49          # compressed wire form (decompression is a "next" row)
+AFFINE_PUBLIC_KEY_LENGTH = 96   # in-memory AffinePoint (x, y): what the engine consumes
+KEY_PAIR_LENGTH = 32
+SIGNATURE_LENGTH = 81
+KEYED_SIGNATURE_LENGTH = 130
+
+OK, INVALID_PUBLIC_KEY, INVALID_SIGNATURE, MALFORMED = 0, 1, 2, 3
+FLAG_CHECK_TORSION = 1
+
+Q = 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
+
+
+class SignatureError(Exception):
+    """src/error.rs:13-31 (Display strings kept verbatim)."""
+    InvalidPublicKey = "InvalidPublicKey"
+    InvalidSignature = "InvalidSignature"
+    _MSG = {
+        "InvalidPublicKey": "The public key is not an element of the prime subgroup.",
+        "InvalidSignature": "The signature is invalid or was incorrectly computed.",
+    }
+
+    def __init__(self, kind):
+        super().__init__(self._MSG[kind])
+        self.kind = kind
+
+    def __repr__(self):
+        return "Err(%s)" % self.kind
+
+
+class MalformedInput(ValueError):
+    """Inputs on which the reference panics (src/signature.rs:186, src/batch.rs:37-44,67)."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "schnorr_sig_amd: HIP library %s is missing; run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64p, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64), C.c_int
+    sigs = {
+        "ssa_ctx_create": (i32, [C.POINTER(vp), i32, vp, sz]),
+        "ssa_ctx_destroy": (None, [vp]),
+        "ssa_strerror": (C.c_char_p, [i32]),
+        "ssa_default_params": (vp, []),
+        "ssa_ctx_set_stream": (i32, [vp, vp]),
+        "ssa_ctx_sync": (i32, [vp]),
+        "ssa_ctx_enable_timing": (i32, [vp, i32]),
+        "ssa_ctx_read_timing": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), u64p]),
+        "ssa_verify": (i32, [vp, vp, vp, vp, sz, u32]),
+        "ssa_verify_many": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
+        "ssa_verify_batch": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, u32]),
+        "ssa_hash_message_many": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
+        "ssa_rescue_hash_many": (i32, [vp, vp, u32, sz, vp]),
+        "ssa_keygen_sign_many": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, vp]),
+        "ssa_verify_many_device": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, vp]),
+        "ssa_hash_message_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
+        "ssa_rescue_hash_many_device": (i32, [vp, vp, u32, sz, vp]),
+        "ssa_keygen_sign_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, vp]),
+        "ssa_debug_arith": (i32, [vp, i32, vp, vp, sz, sz, sz, vp, sz]),
+        "ssa_bench_fpmul": (i32, [vp, i32, C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)      # AttributeError here == ABI symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib, list(sigs)
+
+
+_lib, ABI_SYMBOLS = _load()
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, _lib.ssa_strerror(rc).decode(), rc))
+    return rc
+
+
+def _np_u8(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def pack_messages(messages):
+    """list of bytes -> (concatenated uint8 array, uint64 offsets[n+1])."""
+    off = np.zeros(len(messages) + 1, dtype=np.uint64)
+    if messages:
+        off[1:] = np.cumsum([len(m) for m in messages], dtype=np.uint64)
+    flat = np.frombuffer(b"".join(bytes(m) for m in messages) + b"\0", dtype=np.uint8).copy()
+    return flat, off
+
+
+class Engine:
+    """One ssa_ctx: a device, a stream, the comb table for G and the workspaces."""
+
+    def __init__(self, device=0, params=None):
+        self._ctx = C.c_void_p()
+        blob = None
+        if params is not None:
+            blob = (C.c_uint8 * len(params)).from_buffer_copy(bytes(params))
+        _check(_lib.ssa_ctx_create(C.byref(self._ctx), int(device), blob, len(params) if params else 0),
+               "ssa_ctx_create")
+        self.device = int(device)
+
+    def close(self):
+        if self._ctx:
+            _lib.ssa_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def default_params():
+        return C.string_at(_lib.ssa_default_params(), 2816)
+
+    # ---- host-buffer entry points ------------------------------------------------------
+    def _msg_args(self, msgs, offsets, n):
+        if offsets is not None:
+            m = _np_u8(msgs)
+            off = np.ascontiguousarray(offsets, dtype=np.uint64)
+            assert off.size == n + 1
+            return m, off, 0, 0
+        m = _np_u8(msgs)
+        assert m.ndim == 2 and m.shape[0] == n, "dense messages must be an (n, len) array"
+        return m, None, m.shape[1], m.shape[1]
+
+    def verify_many(self, sigs, pks, msgs, offsets=None, check_torsion=True, pk_inf=None):
+        """n x Signature::verify -> (status uint8[n], n_fail)."""
+        sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
+        n = sigs.shape[0]
+        assert pks.shape[0] == n
+        m, off, stride, mlen = self._msg_args(msgs, offsets, n)
+        inf = _np_u8(pk_inf) if pk_inf is not None else None
+        status = np.full(n, 255, dtype=np.uint8)
+        nfail = C.c_uint64(0)
+        _check(_lib.ssa_verify_many(self._ctx, _ptr(sigs), _ptr(pks), _ptr(inf), _ptr(m), _ptr(off), stride,
+                                    mlen, n, FLAG_CHECK_TORSION if check_torsion else 0, _ptr(status),
+                                    C.byref(nfail)), "ssa_verify_many")
+        return status, int(nfail.value)
+
+    def verify_batch_status(self, sigs, pks, msgs, offsets=None, check_torsion=False):
+        sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
+        n = sigs.shape[0]
+        if pks.shape[0] != n:
+            raise MalformedInput("We should have the same number of signatures than public keys")
+        m, off, stride, mlen = self._msg_args(msgs, offsets, n)
+        return _check(_lib.ssa_verify_batch(self._ctx, _ptr(sigs), _ptr(pks), _ptr(m), _ptr(off), stride, mlen,
+                                            n, FLAG_CHECK_TORSION if check_torsion else 0), "ssa_verify_batch")
+
+    def verify_one(self, sig81, pk96, message, check_torsion=True):
+        sig, pk = _np_u8(bytearray(sig81)), _np_u8(bytearray(pk96))
+        msg = _np_u8(bytearray(bytes(message) + b"\0"))
+        return _check(_lib.ssa_verify(self._ctx, _ptr(sig), _ptr(pk), _ptr(msg), len(message),
+                                      FLAG_CHECK_TORSION if check_torsion else 0), "ssa_verify")
+
+    def hash_message_many(self, sigs, pks, msgs, offsets=None):
+        sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
+        n = sigs.shape[0]
+        m, off, stride, mlen = self._msg_args(msgs, offsets, n)
+        out = np.zeros((n, 32), dtype=np.uint8)
+        _check(_lib.ssa_hash_message_many(self._ctx, _ptr(sigs), _ptr(pks), _ptr(m), _ptr(off), stride, mlen, n,
+                                          _ptr(out)), "ssa_hash_message_many")
+        return out
+
+    def rescue_hash_many(self, felts):
+        f = np.ascontiguousarray(felts, dtype=np.uint64)
+        assert f.ndim == 2
+        out = np.zeros((f.shape[0], 4), dtype=np.uint64)
+        _check(_lib.ssa_rescue_hash_many(self._ctx, _ptr(f), f.shape[1], f.shape[0], _ptr(out)),
+               "ssa_rescue_hash_many")
+        return out
+
+    def keygen_sign_many(self, sks, nonces, msgs, offsets=None):
+        sks, nonces = _np_u8(sks, 32), _np_u8(nonces, 32)
+        n = sks.shape[0]
+        m, off, stride, mlen = self._msg_args(msgs, offsets, n)
+        pks = np.zeros((n, 96), dtype=np.uint8)
+        sigs = np.zeros((n, 81), dtype=np.uint8)
+        _check(_lib.ssa_keygen_sign_many(self._ctx, _ptr(sks), _ptr(nonces), _ptr(m), _ptr(off), stride, mlen, n,
+                                         _ptr(pks), _ptr(sigs)), "ssa_keygen_sign_many")
+        return pks, sigs
+
+    # ---- device-buffer entry points (raw device addresses, e.g. torch.Tensor.data_ptr()) ----
+    def set_stream(self, hip_stream):
+        _check(_lib.ssa_ctx_set_stream(self._ctx, C.c_void_p(hip_stream or 0)), "ssa_ctx_set_stream")
+
+    def sync(self):
+        _check(_lib.ssa_ctx_sync(self._ctx), "ssa_ctx_sync")
+
+    def verify_many_device(self, d_sigs, d_pks, d_msgs, n, msg_len, d_status, d_nfail, msg_stride=None,
+                           d_offsets=0, d_pk_inf=0, check_torsion=False):
+        _check(_lib.ssa_verify_many_device(self._ctx, d_sigs, d_pks, d_pk_inf or None, d_msgs, d_offsets or None,
+                                           msg_stride if msg_stride is not None else msg_len, msg_len, n,
+                                           FLAG_CHECK_TORSION if check_torsion else 0, d_status, d_nfail),
+               "ssa_verify_many_device")
+
+    def keygen_sign_many_device(self, d_sks, d_nonces, d_msgs, n, msg_len, d_pks, d_sigs, msg_stride=None,
+                                d_offsets=0):
+        _check(_lib.ssa_keygen_sign_many_device(self._ctx, d_sks, d_nonces, d_msgs, d_offsets or None,
+                                                msg_stride if msg_stride is not None else msg_len, msg_len, n,
+                                                d_pks, d_sigs), "ssa_keygen_sign_many_device")
+
+    def rescue_hash_many_device(self, d_felts, per_row, n, d_out):
+        _check(_lib.ssa_rescue_hash_many_device(self._ctx, d_felts, per_row, n, d_out),
+               "ssa_rescue_hash_many_device")
+
+    def hash_message_many_device(self, d_sigs, d_pks, d_msgs, n, msg_len, d_out, msg_stride=None, d_offsets=0):
+        _check(_lib.ssa_hash_message_many_device(self._ctx, d_sigs, d_pks, d_msgs, d_offsets or None,
+                                                 msg_stride if msg_stride is not None else msg_len, msg_len, n,
+                                                 d_out), "ssa_hash_message_many_device")
+
+    def enable_timing(self, on=True):
+        _check(_lib.ssa_ctx_enable_timing(self._ctx, int(on)), "ssa_ctx_enable_timing")
+
+    def read_timing(self, kernel):
+        avg = C.c_double(0)
+        cnt = C.c_uint64(0)
+        _check(_lib.ssa_ctx_read_timing(self._ctx, kernel.encode(), C.byref(avg), C.byref(cnt)),
+               "ssa_ctx_read_timing")
+        return avg.value, int(cnt.value)
+
+    # ---- probes --------------------------------------------------------------------------
+    def debug_arith(self, op, a, b, out_cols):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
+        n = a.shape[0]
+        out = np.zeros((n, out_cols), dtype=np.uint64)
+        _check(_lib.ssa_debug_arith(self._ctx, op, _ptr(a), _ptr(b), n, a.shape[1],
+                                    b.shape[1] if b is not None else 0, _ptr(out), out_cols), "ssa_debug_arith")
+        return out
+
+    def bench_fpmul(self, variant):
+        v = C.c_double(0)
+        _check(_lib.ssa_bench_fpmul(self._ctx, variant, C.byref(v)), "ssa_bench_fpmul")
+        return v.value
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+# ------------------------------------------------------------------------------------------
+# Object mirror of the reference's types (thin; bytes in, bytes out)
+# ------------------------------------------------------------------------------------------
+class PublicKey:
+    """PublicKey(AffinePoint) (src/public.rs:24): 96 bytes affine x || y, canonical LE limbs."""
+
+    def __init__(self, affine96):
+        b = bytes(affine96)
+        if len(b) != AFFINE_PUBLIC_KEY_LENGTH:
+            raise ValueError("PublicKey needs 96 bytes of affine coordinates")
+        self.affine = b
+
+    def verify_signature(self, signature, message):  # src/signature.rs:170-176
+        return signature.verify(message, self)
+
+    def __eq__(self, o):
+        return isinstance(o, PublicKey) and o.affine == self.affine
+
+
+class PrivateKey:
+    """PrivateKey(Scalar) (src/private.rs:25): 32 bytes LE, canonical, non-zero."""
+
+    def __init__(self, scalar32):
+        b = bytes(scalar32)
+        v = int.from_bytes(b, "little")
+        if len(b) != 32 or v == 0 or v >= Q:
+            raise ValueError("invalid private key encoding")   # from_bytes is_none, src/private.rs:74-76
+        self.bytes = b
+
+    @classmethod
+    def new(cls, rng):  # src/private.rs:49-57
+        while True:
+            v = int.from_bytes(rng(64), "little") % Q
+            if v:
+                return cls(v.to_bytes(32, "little"))
+
+    def to_bytes(self):
+        return self.bytes
+
+
+class Signature:
+    """Signature{x: CompressedPoint, e: Scalar} (src/signature.rs:34-40), 81 bytes."""
+
+    def __init__(self, sig81):
+        b = bytes(sig81)
+        if len(b) != SIGNATURE_LENGTH:
+            raise ValueError("Signature needs 81 bytes")
+        self.bytes = b
+
+    @classmethod
+    def from_bytes(cls, b):  # src/signature.rs:217-227: None when e is not canonical
+        if int.from_bytes(bytes(b)[49:81], "little") >= Q:
+            return None
+        return cls(b)
+
+    def to_bytes(self):
+        return self.bytes
+
+    def verify(self, message, pkey, engine=None):
+        """Ok -> None; otherwise raises SignatureError (src/signature.rs:181-205)."""
+        st = (engine or default_engine()).verify_one(self.bytes, pkey.affine, message, check_torsion=True)
+        if st == OK:
+            return None
+        if st == INVALID_PUBLIC_KEY:
+            raise SignatureError(SignatureError.InvalidPublicKey)
+        if st == INVALID_SIGNATURE:
+            raise SignatureError(SignatureError.InvalidSignature)
+        raise MalformedInput("non-canonical field element or scalar (the reference panics here)")
+
+    def __eq__(self, o):
+        return isinstance(o, Signature) and o.bytes == self.bytes
+
+
+class KeyPair:
+    """KeyPair{private_key, public_key} (src/keypair.rs:48-53)."""
+
+    def __init__(self, private_key, public_key):
+        self.private_key = private_key
+        self.public_key = public_key
+
+    @classmethod
+    def new(cls, rng, engine=None):  # src/keypair.rs:57-65
+        return cls.from_private(PrivateKey.new(rng), engine)
+
+    @classmethod
+    def from_private(cls, sk, engine=None):  # PublicKey::from(&PrivateKey), src/public.rs:26-32
+        eng = engine or default_engine()
+        pks, _ = eng.keygen_sign_many(np.frombuffer(sk.bytes, np.uint8), np.frombuffer(sk.bytes, np.uint8),
+                                      np.zeros((1, 1), np.uint8))
+        return cls(sk, PublicKey(pks[0].tobytes()))
+
+    def sign(self, message, rng, engine=None):  # src/signature.rs:114-129
+        eng = engine or default_engine()
+        nonce = (int.from_bytes(rng(64), "little") % Q).to_bytes(32, "little")
+        msg = np.frombuffer(bytes(message) + b"\0", np.uint8).copy()
+        off = np.array([0, len(message)], dtype=np.uint64)
+        _, sigs = eng.keygen_sign_many(np.frombuffer(self.private_key.bytes, np.uint8),
+                                       np.frombuffer(nonce, np.uint8), msg, offsets=off)
+        return Signature(sigs[0].tobytes())
+
+    def verify_signature(self, signature, message):  # src/signature.rs:159-165
+        return signature.verify(message, self.public_key)
+
+
+def verify_batch(signatures, public_keys, messages, rng=None, engine=None):
+    """verify_batch (src/batch.rs:31-50): Ok -> None, else raises SignatureError.
+    `rng` is accepted for signature compatibility and unused: the engine checks every
+    signature exactly instead of a random linear combination (divergence classes)."""
+    if len(signatures) != len(public_keys):
+        raise MalformedInput("We should have the same number of signatures than public keys")
+    if len(messages) != len(public_keys):
+        raise MalformedInput("We should have the same number of messages than public keys")
+    if not signatures:
+        return None
+    eng = engine or default_engine()
+    sigs = np.frombuffer(b"".join(s.bytes for s in signatures), np.uint8)
+    pks = np.frombuffer(b"".join(p.affine for p in public_keys), np.uint8)
+    flat, off = pack_messages(messages)
+    st = eng.verify_batch_status(sigs, pks, flat, offsets=off, check_torsion=False)
+    if st == OK:
+        return None
+    if st == MALFORMED:
+        raise MalformedInput("undecodable signature in batch (the reference panics here)")
+    raise SignatureError(SignatureError.InvalidSignature)

@@ -1,0 +1,218 @@
+// Cheetah curve  y^2 = x^3 + x + (u + 395)  over Fp6 (reference README.md:4-9) and 256-bit
+// scalars mod q, for the verification path (cheetah::AffinePoint::
+// multiply_double_with_basepoint_vartime / is_torsion_free, called at
+// src/signature.rs:182,196-198).  Jacobian coordinates, a = 1; Z == 0 encodes the identity.
+//
+// E(Fp6) has even order, so every addition handles P == +-Q and the identity explicitly
+// (adversarial e can steer the accumulator onto a table point); doublings need no special
+// case (Y == 0 or Z == 0 both give Z3 == 0).
+#pragma once
+#include "fp6.cuh"
+
+namespace ssa {
+
+struct jac {
+    fp6 X, Y, Z;
+};
+struct aff {
+    fp6 x, y;
+};
+
+SSA_DEV jac jac_identity() {
+    jac r;
+    r.X = f6_one();
+    r.Y = f6_one();
+    r.Z = f6_zero();
+    return r;
+}
+SSA_DEV bool jac_is_identity(const jac &p) { return f6_is_zero(p.Z); }
+
+// dbl-2007-bl with a = 1: 1M + 8S
+SSA_DEV jac jac_dbl(const jac &p) {
+    fp6 XX = f6_sqr(p.X);
+    fp6 YY = f6_sqr(p.Y);
+    fp6 YYYY = f6_sqr(YY);
+    fp6 ZZ = f6_sqr(p.Z);
+    fp6 t = f6_add(p.X, YY);
+    fp6 S = f6_dbl(f6_sub(f6_sub(f6_sqr(t), XX), YYYY));
+    fp6 M = f6_add(f6_add(f6_dbl(XX), XX), f6_sqr(ZZ));
+    jac r;
+    r.X = f6_sub(f6_sqr(M), f6_dbl(S));
+    fp6 y8 = f6_dbl(f6_dbl(f6_dbl(YYYY)));
+    r.Y = f6_sub(f6_mul(M, f6_sub(S, r.X)), y8);
+    fp6 yz = f6_add(p.Y, p.Z);
+    r.Z = f6_sub(f6_sub(f6_sqr(yz), YY), ZZ);
+    return r;
+}
+
+// mixed addition p + (x2, y2); q_inf marks q as the identity.  7M + 4S on the generic path.
+SSA_DEV jac jac_madd(const jac &p, const aff &q) {
+    fp6 Z1Z1 = f6_sqr(p.Z);
+    fp6 U2 = f6_mul(q.x, Z1Z1);
+    fp6 S2 = f6_mul(f6_mul(q.y, p.Z), Z1Z1);
+    fp6 H = f6_sub(U2, p.X);
+    fp6 R = f6_sub(S2, p.Y);
+    const bool p_inf = f6_is_zero(p.Z);
+    const bool h0 = f6_is_zero(H);
+    const bool r0 = f6_is_zero(R);
+    if (!p_inf && h0 && r0) return jac_dbl(p);  // p == q (rare, divergent)
+    fp6 HH = f6_sqr(H);
+    fp6 HHH = f6_mul(H, HH);
+    fp6 V = f6_mul(p.X, HH);
+    jac r;
+    r.X = f6_sub(f6_sub(f6_sqr(R), HHH), f6_dbl(V));
+    r.Y = f6_sub(f6_mul(R, f6_sub(V, r.X)), f6_mul(p.Y, HHH));
+    r.Z = f6_mul(p.Z, H);  // H == 0, R != 0  =>  Z3 = 0: p == -q gives the identity
+    if (p_inf) {
+        r.X = q.x;
+        r.Y = q.y;
+        r.Z = f6_one();
+    }
+    return r;
+}
+
+// general addition p + q (both Jacobian): 11M + 5S on the generic path
+SSA_DEV jac jac_add(const jac &p, const jac &q) {
+    fp6 Z1Z1 = f6_sqr(p.Z);
+    fp6 Z2Z2 = f6_sqr(q.Z);
+    fp6 U1 = f6_mul(p.X, Z2Z2);
+    fp6 U2 = f6_mul(q.X, Z1Z1);
+    fp6 S1 = f6_mul(f6_mul(p.Y, q.Z), Z2Z2);
+    fp6 S2 = f6_mul(f6_mul(q.Y, p.Z), Z1Z1);
+    fp6 H = f6_sub(U2, U1);
+    fp6 R = f6_sub(S2, S1);
+    const bool p_inf = f6_is_zero(p.Z);
+    const bool q_inf = f6_is_zero(q.Z);
+    if (!p_inf && !q_inf && f6_is_zero(H) && f6_is_zero(R)) return jac_dbl(p);
+    fp6 HH = f6_sqr(H);
+    fp6 HHH = f6_mul(H, HH);
+    fp6 V = f6_mul(U1, HH);
+    jac r;
+    r.X = f6_sub(f6_sub(f6_sqr(R), HHH), f6_dbl(V));
+    r.Y = f6_sub(f6_mul(R, f6_sub(V, r.X)), f6_mul(S1, HHH));
+    r.Z = f6_mul(f6_mul(p.Z, q.Z), H);
+    if (p_inf) r = q;
+    if (q_inf && !p_inf) r = p;
+    return r;
+}
+
+SSA_DEV jac jac_neg_if(const jac &p, bool neg) {
+    jac r = p;
+    fp6 ny = f6_neg(p.Y);
+    r.Y = f6_select(neg, p.Y, ny);
+    return r;
+}
+
+SSA_DEV jac jac_from_aff(const aff &a) {
+    jac r;
+    r.X = a.x;
+    r.Y = a.y;
+    r.Z = f6_one();
+    return r;
+}
+
+// affine x, y of a finite point (canonical limbs); the identity maps to (0, 0)
+SSA_DEV aff jac_to_aff(const jac &p) {
+    aff r;
+    if (f6_is_zero(p.Z)) {
+        r.x = f6_zero();
+        r.y = f6_zero();
+        return r;
+    }
+    fp6 zi = f6_inv(p.Z);
+    fp6 zi2 = f6_sqr(zi);
+    r.x = f6_canon(f6_mul(p.X, zi2));
+    r.y = f6_canon(f6_mul(p.Y, f6_mul(zi, zi2)));
+    return r;
+}
+
+// ------------------------------------------------------------------ scalars (4 x u64, LE)
+struct sc256 {
+    u64 w[4];
+};
+// q = 0x7af2599b3b3f22d0563fbf0f990a37b5327aa72330157722d443623eaed4accf (prime subgroup order)
+SSA_DEV u64 sc_q_limb(int i) {
+    switch (i) {
+        case 0: return 0xd443623eaed4accfULL;
+        case 1: return 0x327aa72330157722ULL;
+        case 2: return 0x563fbf0f990a37b5ULL;
+        default: return 0x7af2599b3b3f22d0ULL;
+    }
+}
+#define SC_Q(i) sc_q_limb(i)
+
+SSA_DEV bool sc_geq_q(const sc256 &a) {
+    bool ge = true;  // equal so far => >=
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // from least to most significant: later limbs override
+        if (a.w[i] > SC_Q(i)) ge = true;
+        if (a.w[i] < SC_Q(i)) ge = false;
+    }
+    return ge;
+}
+SSA_DEV sc256 sc_sub_q(const sc256 &a) {
+    sc256 r;
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 d = a.w[i] - SC_Q(i);
+        u64 b1 = a.w[i] < SC_Q(i);
+        u64 d2 = d - borrow;
+        u64 b2 = d < borrow;
+        r.w[i] = d2;
+        borrow = b1 | b2;
+    }
+    return r;
+}
+// any 256-bit value mod q: floor(2^256 / q) = 2 (Scalar::from_bits_vartime, src/signature.rs:189-192)
+SSA_DEV sc256 sc_reduce256(sc256 a) {
+    if (sc_geq_q(a)) a = sc_sub_q(a);
+    if (sc_geq_q(a)) a = sc_sub_q(a);
+    return a;
+}
+
+// Offset recoding for signed 4-bit windows: k' = k + 0x88..8 (mod 2^256) and carry-out;
+// digit_w = nibble_w(k') - 8 in [-8, 7],  k = carry*16^64 + sum digit_w 16^w.
+SSA_DEV sc256 sc_recode_offset(const sc256 &k, u32 &carry_out) {
+    sc256 r;
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 s = k.w[i] + 0x8888888888888888ULL;
+        u64 c1 = s < k.w[i];
+        u64 s2 = s + carry;
+        u64 c2 = s2 < s;
+        r.w[i] = s2;
+        carry = c1 | c2;
+    }
+    carry_out = (u32)carry;
+    return r;
+}
+// nibble w (0..63) of a 256-bit value with a dynamic index, registers only
+SSA_DEV u32 sc_nibble(const sc256 &k, u32 w) {
+    const u32 wi = w >> 4;
+    u64 word = k.w[0];
+    if (wi == 1) word = k.w[1];
+    if (wi == 2) word = k.w[2];
+    if (wi == 3) word = k.w[3];
+    return (u32)(word >> ((w & 15u) * 4u)) & 15u;
+}
+// 16-bit window w (0..15)
+SSA_DEV u32 sc_win16(const sc256 &k, u32 w) {
+    const u32 wi = w >> 2;
+    u64 word = k.w[0];
+    if (wi == 1) word = k.w[1];
+    if (wi == 2) word = k.w[2];
+    if (wi == 3) word = k.w[3];
+    return (u32)(word >> ((w & 3u) * 16u)) & 0xffffu;
+}
+
+// Curve equation check y^2 == x^3 + x + (u + 395)
+SSA_DEV bool aff_on_curve(const aff &p) {
+    fp6 rhs = f6_add(f6_mul(f6_sqr(p.x), p.x), p.x);
+    rhs.c[0] = fp_add(rhs.c[0], 395ull);
+    rhs.c[1] = fp_add(rhs.c[1], 1ull);
+    return f6_eq(f6_sqr(p.y), rhs);
+}
+
+}  // namespace ssa

@@ -1,0 +1,129 @@
+// Rescue-Prime 64/12/8 over Goldilocks (reference: hash::rescue_64_12_8::RescueHash, imported
+// at src/signature.rs:21-24 and called at :303-305) and the hash_message felt packing
+// (src/signature.rs:274-306).  All constants come from the parameter blob (ssa_params): the
+// upstream values are unpinned, so nothing here is hard-coded except alpha = 7.
+#pragma once
+#include "fp.cuh"
+
+namespace ssa {
+
+// Device image of the parameter blob (include/schnorr_sig_amd.h: ssa_params, 2816 bytes).
+struct DevParams {
+    char magic[8];
+    u32 n_rounds, rate_off;
+    int cap_len_idx;
+    u32 pad_mode, digest_off, flags;
+    u64 mds[144];
+    u64 ark1[96];
+    u64 ark2[96];
+    u64 gen_x[6], gen_y[6];
+};
+static_assert(sizeof(DevParams) == 2816, "blob layout");
+
+// x^7: 2 squarings + 2 products
+SSA_DEV u64 sbox(u64 x) {
+    u64 x2 = fp_sqr(x);
+    u64 x4 = fp_sqr(x2);
+    return fp_mul(fp_mul(x4, x2), x);
+}
+
+template <int N>
+SSA_DEV u64 sqr_n_mul(u64 base, u64 tail) {
+    u64 r = base;
+#pragma unroll 1
+    for (int i = 0; i < N; i++) r = fp_sqr(r);
+    return fp_mul(r, tail);
+}
+
+// x^(1/7) = x^0x92492491b6db6db7: 63 squarings + 9 products
+SSA_DEV u64 inv_sbox(u64 x) {
+    u64 t1 = fp_sqr(x);
+    u64 t2 = fp_sqr(t1);
+    u64 t3 = sqr_n_mul<3>(t2, t2);
+    u64 t4 = sqr_n_mul<6>(t3, t3);
+    u64 t5 = sqr_n_mul<12>(t4, t4);
+    u64 t6 = sqr_n_mul<6>(t5, t3);
+    u64 t7 = sqr_n_mul<31>(t6, t6);
+    u64 a = fp_mul(fp_sqr(t7), t6);
+    a = fp_sqr(fp_sqr(a));
+    u64 b = fp_mul(fp_mul(t1, t2), x);
+    return fp_mul(a, b);
+}
+
+// The 12-felt sponge state of a lane lives in LDS ("LDS-staged"): plane element i of lane t is
+// st[i * RS_STRIDE + t], so dynamic indexing costs a ds_read/ds_write instead of forcing the
+// whole permutation to be unrolled (17k instructions when it was register-resident; the
+// rolled form is ~2k and stays in the instruction cache).  Two planes ping-pong through the
+// MDS layers: 2 x 12 x 8 B = 192 B per lane, 48 KB per 256-thread block.
+constexpr int RS_STRIDE = 256;  // == blockDim.x of every kernel that hashes
+constexpr int RS_LDS_U64 = 2 * 12 * RS_STRIDE;
+
+// dst <- MDS * src + ark (lazy 12-term accumulation per output, one reduction each)
+SSA_DEV void mds_ark(const u64 *src, u64 *dst, const u64 *__restrict__ mds, const u64 *__restrict__ ark) {
+    u64 v[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) v[j] = src[j * RS_STRIDE];
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        const u64 *row = mds + i * 12;
+        fp_acc acc;
+        acc_init(acc, v[0], row[0]);
+#pragma unroll
+        for (int j = 1; j < 12; j++) acc_mac(acc, v[j], row[j]);
+        dst[i * RS_STRIDE] = fp_add(acc_reduce(acc), ark[i]);
+    }
+}
+
+// permutation of the state in plane A (plane B is scratch); result back in plane A
+SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ prm) {
+    const u32 nr = prm->n_rounds;
+#pragma unroll 1
+    for (u32 r = 0; r < nr; r++) {
+#pragma unroll 1
+        for (int i = 0; i < 6; i++) {  // two independent chains per iteration
+            const u64 x = sbox(A[i * RS_STRIDE]), y = sbox(A[(i + 6) * RS_STRIDE]);
+            A[i * RS_STRIDE] = x;
+            A[(i + 6) * RS_STRIDE] = y;
+        }
+        mds_ark(A, B, prm->mds, prm->ark1 + 12 * r);
+#pragma unroll 1
+        for (int i = 0; i < 6; i++) {
+            const u64 x = inv_sbox(B[i * RS_STRIDE]), y = inv_sbox(B[(i + 6) * RS_STRIDE]);
+            B[i * RS_STRIDE] = x;
+            B[(i + 6) * RS_STRIDE] = y;
+        }
+        mds_ark(B, A, prm->mds, prm->ark2 + 12 * r);
+    }
+}
+
+// Rate-8 additive sponge (Hasher::hash_field) driven by a felt source `src(idx)`.
+//   A, B     : this lane's columns of the two LDS planes
+//   n_felts  : number of felts absorbed by this lane (13 + message felts for hash_message)
+template <class Src>
+SSA_DEV void sponge_hash(u64 *A, u64 *B, const DevParams *__restrict__ prm, u32 n_felts, Src src,
+                         u64 (&digest)[4]) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) A[i * RS_STRIDE] = 0ull;
+    if (prm->cap_len_idx >= 0) A[prm->cap_len_idx * RS_STRIDE] = (u64)n_felts;
+    const u32 rate_off = prm->rate_off;
+    const bool pad1 = prm->pad_mode == 1;
+    const u32 n_blocks = pad1 ? n_felts / 8 + 1 : (n_felts + 7) / 8;
+#pragma unroll 1
+    for (u32 b = 0; b < n_blocks; b++) {
+#pragma unroll 1
+        for (u32 j = 0; j < 8; j++) {
+            const u32 idx = 8 * b + j;
+            u64 *slot = A + (rate_off + j) * RS_STRIDE;
+            if (idx < n_felts)
+                *slot = fp_add(*slot, src(idx));
+            else if (pad1 && idx == n_felts)
+                *slot = fp_add(*slot, 1ull);
+        }
+        rescue_permutation(A, B, prm);
+    }
+    const u32 off = prm->digest_off;
+#pragma unroll
+    for (int k = 0; k < 4; k++) digest[k] = fp_canon(A[(off + k) * RS_STRIDE]);
+}
+
+}  // namespace ssa

@@ -1,0 +1,548 @@
+// C ABI (include/schnorr_sig_amd.h) over the HIP kernels in ssa_kernels.cuh.
+// No CPU compute path exists here: every entry point launches kernels on the context's
+// device or fails with an SSA_ERR_* code.
+#include "../../include/schnorr_sig_amd.h"
+#include "ssa_kernels.cuh"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ssa;
+
+static const unsigned char k_default_params[SSA_PARAMS_LENGTH] = {
+#include "../params/params_default.inc"
+};
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t err__ = (expr);                                                       \
+        if (err__ != hipSuccess) {                                                       \
+            std::fprintf(stderr, "[schnorr_sig_amd] %s failed: %s (%s:%d)\n", #expr,     \
+                         hipGetErrorString(err__), __FILE__, __LINE__);                  \
+            return SSA_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) return SSA_ERR_HIP;
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+};
+
+struct ssa_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    DevParams *d_params = nullptr;
+    u64 *d_gtab = nullptr;
+    DevBuf ws_h, ws_tab, ws_fail;
+    // staging for the host-buffer entry points
+    DevBuf st_sigs, st_pks, st_inf, st_msgs, st_off, st_status, st_aux, st_aux2;
+    bool timing = false;
+    std::map<std::string, std::vector<TimedLaunch>> timed;
+};
+
+static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+template <class F>
+static int timed_launch(ssa_ctx *ctx, const char *name, F &&launch) {
+    if (!ctx->timing) {
+        launch();
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    TimedLaunch t;
+    HIP_TRY(hipEventCreate(&t.start));
+    HIP_TRY(hipEventCreate(&t.stop));
+    HIP_TRY(hipEventRecord(t.start, ctx->stream));
+    launch();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(t.stop, ctx->stream));
+    ctx->timed[name].push_back(t);
+    return 0;
+}
+
+extern "C" const char *ssa_strerror(int rc) {
+    switch (rc) {
+        case SSA_OK: return "ok";
+        case SSA_INVALID_PUBLIC_KEY: return "The public key is not an element of the prime subgroup.";
+        case SSA_INVALID_SIGNATURE: return "The signature is invalid or was incorrectly computed.";
+        case SSA_MALFORMED: return "malformed input (the reference would panic)";
+        case SSA_ERR_ARG: return "invalid argument";
+        case SSA_ERR_HIP: return "HIP runtime error";
+        case SSA_ERR_PARAMS: return "invalid parameter blob";
+        case SSA_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown";
+    }
+}
+
+extern "C" const void *ssa_default_params(void) { return k_default_params; }
+
+static int validate_params(const DevParams &p) {
+    if (std::memcmp(p.magic, "SSAPARM1", 8) != 0) return SSA_ERR_PARAMS;
+    if (p.n_rounds == 0 || p.n_rounds > 8) return SSA_ERR_PARAMS;
+    if (p.rate_off != 0 && p.rate_off != 4) return SSA_ERR_PARAMS;
+    if (p.cap_len_idx < -1 || p.cap_len_idx > 11) return SSA_ERR_PARAMS;
+    if (p.pad_mode > 1 || p.digest_off > 8) return SSA_ERR_PARAMS;
+    for (int i = 0; i < 144; i++)
+        if (p.mds[i] >= FP_P) return SSA_ERR_PARAMS;
+    for (int i = 0; i < 96; i++)
+        if (p.ark1[i] >= FP_P || p.ark2[i] >= FP_P) return SSA_ERR_PARAMS;
+    for (int i = 0; i < 6; i++)
+        if (p.gen_x[i] >= FP_P || p.gen_y[i] >= FP_P) return SSA_ERR_PARAMS;
+    return 0;
+}
+
+extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, size_t params_len) {
+    if (!out) return SSA_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return SSA_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return SSA_ERR_ARG;
+    DevParams hp;
+    if (params) {
+        if (params_len != sizeof(DevParams)) return SSA_ERR_PARAMS;
+        std::memcpy(&hp, params, sizeof hp);
+    } else {
+        std::memcpy(&hp, k_default_params, sizeof hp);
+    }
+    if (int rc = validate_params(hp)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    ssa_ctx *ctx = new ssa_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return SSA_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    if (hipMalloc((void **)&ctx->d_params, sizeof(DevParams)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_gtab, GTAB_ENTRIES * 12 * sizeof(u64)) != hipSuccess) {
+        ssa_ctx_destroy(ctx);
+        return SSA_ERR_HIP;
+    }
+    if (hipMemcpy(ctx->d_params, &hp, sizeof hp, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemsetAsync(ctx->d_gtab, 0, GTAB_ENTRIES * 12 * sizeof(u64), ctx->stream) != hipSuccess) {
+        ssa_ctx_destroy(ctx);
+        return SSA_ERR_HIP;
+    }
+    // the generator must be on the curve; checked on the device while building the comb table
+    hipLaunchKernelGGL(ssa_k_gtable, dim3(grid_for(GTAB_ENTRIES, 256)), dim3(256), 0, ctx->stream,
+                       ctx->d_params, ctx->d_gtab);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ssa_ctx_destroy(ctx);
+        return SSA_ERR_HIP;
+    }
+    if (ctx->ws_fail.reserve(64)) {
+        ssa_ctx_destroy(ctx);
+        return SSA_ERR_HIP;
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->timed)
+        for (auto &t : kv.second) {
+            (void)hipEventDestroy(t.start);
+            (void)hipEventDestroy(t.stop);
+        }
+    for (DevBuf *b : {&ctx->ws_h, &ctx->ws_tab, &ctx->ws_fail, &ctx->st_sigs, &ctx->st_pks, &ctx->st_inf,
+                      &ctx->st_msgs, &ctx->st_off, &ctx->st_status, &ctx->st_aux, &ctx->st_aux2})
+        b->release();
+    if (ctx->d_params) (void)hipFree(ctx->d_params);
+    if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int ssa_ctx_set_stream(ssa_ctx *ctx, void *hip_stream) {
+    if (!ctx) return SSA_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
+
+extern "C" int ssa_ctx_sync(ssa_ctx *ctx) {
+    if (!ctx) return SSA_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int ssa_ctx_enable_timing(ssa_ctx *ctx, int on) {
+    if (!ctx) return SSA_ERR_ARG;
+    ctx->timing = on != 0;
+    return 0;
+}
+
+extern "C" int ssa_ctx_read_timing(ssa_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches) {
+    if (!ctx || !kernel) return SSA_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    auto it = ctx->timed.find(kernel);
+    double total = 0;
+    uint64_t cnt = 0;
+    if (it != ctx->timed.end()) {
+        for (auto &t : it->second) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+                total += ms;
+                cnt++;
+            }
+            (void)hipEventDestroy(t.start);
+            (void)hipEventDestroy(t.stop);
+        }
+        ctx->timed.erase(it);
+    }
+    if (avg_ms) *avg_ms = cnt ? total / (double)cnt : 0.0;
+    if (launches) *launches = cnt;
+    return 0;
+}
+
+// ------------------------------------------------------------------ device entry points
+static int check_msgs(const uint8_t *msgs, const uint64_t *off, size_t stride, size_t len, size_t n) {
+    if (n == 0) return 0;
+    if (!off && len > 0 && !msgs) return SSA_ERR_ARG;
+    if (!off && stride < len) return SSA_ERR_ARG;
+    if (len > 0xffffffffull) return SSA_ERR_ARG;
+    return 0;
+}
+
+extern "C" int ssa_hash_message_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
+                                            const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                            size_t msg_stride, size_t msg_len, size_t n,
+                                            uint8_t *d_digests_out) {
+    if (!ctx || (n && (!d_sigs || !d_pks || !d_digests_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
+    return timed_launch(ctx, "ssa_k_hash", [&] {
+        hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                           d_sigs, d_pks, mv, n, (u64 *)nullptr, d_digests_out);
+    });
+}
+
+extern "C" int ssa_rescue_hash_many_device(ssa_ctx *ctx, const uint64_t *d_felts, uint32_t felts_per_row,
+                                           size_t n, uint64_t *d_digests_out) {
+    if (!ctx || (n && (!d_digests_out || (felts_per_row && !d_felts)))) return SSA_ERR_ARG;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return timed_launch(ctx, "ssa_k_rescue", [&] {
+        hipLaunchKernelGGL(ssa_k_rescue, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                           (const u64 *)d_felts, felts_per_row, n, (u64 *)d_digests_out);
+    });
+}
+
+extern "C" int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
+                                      const uint8_t *d_pk_inf, const uint8_t *d_msgs,
+                                      const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len,
+                                      size_t n, uint32_t flags, uint8_t *d_status_out,
+                                      uint64_t *d_n_fail_out) {
+    if (!ctx || (n && (!d_sigs || !d_pks || !d_status_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long *d_fail = d_n_fail_out ? (unsigned long long *)d_n_fail_out
+                                              : (unsigned long long *)ctx->ws_fail.p;
+    HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), ctx->stream));
+    if (n == 0) return 0;
+    if (ctx->ws_h.reserve(n * 4 * sizeof(u64))) return SSA_ERR_HIP;
+    if (ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
+    MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
+    int rc = timed_launch(ctx, "ssa_k_hash", [&] {
+        hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                           d_sigs, d_pks, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr);
+    });
+    if (rc) return rc;
+    return timed_launch(ctx, "ssa_k_verify", [&] {
+        hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_sigs, d_pks,
+                           d_pk_inf, (const u64 *)ctx->ws_h.p, (const u64 *)ctx->d_gtab,
+                           (u64 *)ctx->ws_tab.p, n, flags, d_status_out, d_fail);
+    });
+}
+
+extern "C" int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces,
+                                           const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                           size_t msg_stride, size_t msg_len, size_t n,
+                                           uint8_t *d_pks_out, uint8_t *d_sigs_out) {
+    if (!ctx || (n && (!d_sks || !d_nonces || !d_pks_out || !d_sigs_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
+    return timed_launch(ctx, "ssa_k_sign", [&] {
+        hipLaunchKernelGGL(ssa_k_sign, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                           (const u64 *)ctx->d_gtab, d_sks, d_nonces, mv, n, d_pks_out, d_sigs_out);
+    });
+}
+
+// ------------------------------------------------------------------ host entry points
+static size_t msgs_bytes(const uint64_t *off, size_t stride, size_t len, size_t n) {
+    if (n == 0) return 0;
+    if (off) return (size_t)off[n];
+    return (n - 1) * stride + len;
+}
+
+struct StagedInputs {
+    const u8 *sigs = nullptr, *pks = nullptr, *inf = nullptr, *msgs = nullptr;
+    const u64 *off = nullptr;
+};
+
+static int stage_up(ssa_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, const void **dst) {
+    *dst = nullptr;
+    if (!src || bytes == 0) {
+        if (buf.reserve(16)) return SSA_ERR_HIP;  // non-null dummy for zero-length messages
+        *dst = src ? buf.p : nullptr;
+        return 0;
+    }
+    if (buf.reserve(bytes)) return SSA_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dst = buf.p;
+    return 0;
+}
+
+static int stage_msgs(ssa_ctx *ctx, const uint8_t *msgs, const uint64_t *off, size_t stride, size_t len,
+                      size_t n, StagedInputs &s) {
+    const void *p;
+    if (off) {
+        for (size_t i = 0; i < n; i++)
+            if (off[i + 1] < off[i] || off[i + 1] - off[i] > 0xffffffffull) return SSA_ERR_ARG;
+        if (int rc = stage_up(ctx, ctx->st_off, off, (n + 1) * sizeof(uint64_t), &p)) return rc;
+        s.off = (const u64 *)p;
+    }
+    const size_t mb = msgs_bytes(off, stride, len, n);
+    if (mb && !msgs) return SSA_ERR_ARG;
+    if (ctx->st_msgs.reserve(mb + 16)) return SSA_ERR_HIP;
+    if (mb) HIP_TRY(hipMemcpyAsync(ctx->st_msgs.p, msgs, mb, hipMemcpyHostToDevice, ctx->stream));
+    s.msgs = (const u8 *)ctx->st_msgs.p;
+    return 0;
+}
+
+extern "C" int ssa_verify_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                               const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
+                               size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,
+                               uint64_t *n_fail_out) {
+    if (!ctx || (n && (!sigs || !pks || !status_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (n_fail_out) *n_fail_out = 0;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    StagedInputs s;
+    const void *p;
+    if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;
+    s.sigs = (const u8 *)p;
+    if (int rc = stage_up(ctx, ctx->st_pks, pks, n * 96, &p)) return rc;
+    s.pks = (const u8 *)p;
+    if (pk_inf) {
+        if (int rc = stage_up(ctx, ctx->st_inf, pk_inf, n, &p)) return rc;
+        s.inf = (const u8 *)p;
+    }
+    if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
+    if (ctx->st_status.reserve(n + 16)) return SSA_ERR_HIP;
+    unsigned long long *d_fail = (unsigned long long *)ctx->ws_fail.p;
+    if (int rc = ssa_verify_many_device(ctx, s.sigs, s.pks, s.inf, s.msgs, s.off, msg_stride, msg_len, n,
+                                        flags, (u8 *)ctx->st_status.p, (uint64_t *)d_fail))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(status_out, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long nf = 0;
+    HIP_TRY(hipMemcpyAsync(&nf, d_fail, sizeof nf, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_fail_out) *n_fail_out = nf;
+    return 0;
+}
+
+extern "C" int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
+                                const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                                uint32_t flags) {
+    if (n == 0) return ctx ? SSA_OK : SSA_ERR_ARG;  // empty batch verifies (src/batch.rs)
+    std::vector<uint8_t> status(n);
+    uint64_t nf = 0;
+    if (int rc = ssa_verify_many(ctx, sigs, pks, nullptr, msgs, msg_off, msg_stride, msg_len, n, flags,
+                                 status.data(), &nf))
+        return rc;
+    if (nf == 0) return SSA_OK;
+    int worst = SSA_MALFORMED + 1;
+    for (uint8_t s : status)
+        if (s != SSA_OK && s < worst) worst = s;
+    return worst;
+}
+
+extern "C" int ssa_verify(ssa_ctx *ctx, const uint8_t sig[SSA_SIGNATURE_LENGTH],
+                          const uint8_t pk[SSA_AFFINE_PK_LENGTH], const uint8_t *msg, size_t msg_len,
+                          uint32_t flags) {
+    uint8_t st = SSA_MALFORMED;
+    if (int rc = ssa_verify_many(ctx, sig, pk, nullptr, msg, nullptr, msg_len, msg_len, 1, flags, &st, nullptr))
+        return rc;
+    return st;
+}
+
+extern "C" int ssa_hash_message_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
+                                     const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                                     uint8_t *digests_out) {
+    if (!ctx || (n && (!sigs || !pks || !digests_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    StagedInputs s;
+    const void *p;
+    if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;
+    s.sigs = (const u8 *)p;
+    if (int rc = stage_up(ctx, ctx->st_pks, pks, n * 96, &p)) return rc;
+    s.pks = (const u8 *)p;
+    if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
+    if (ctx->st_aux.reserve(n * 32)) return SSA_ERR_HIP;
+    if (int rc = ssa_hash_message_many_device(ctx, s.sigs, s.pks, s.msgs, s.off, msg_stride, msg_len, n,
+                                              (u8 *)ctx->st_aux.p))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(digests_out, ctx->st_aux.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int ssa_rescue_hash_many(ssa_ctx *ctx, const uint64_t *felts, uint32_t felts_per_row, size_t n,
+                                    uint64_t *digests_out) {
+    if (!ctx || (n && (!digests_out || (felts_per_row && !felts)))) return SSA_ERR_ARG;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const void *p;
+    if (int rc = stage_up(ctx, ctx->st_aux, felts, n * (size_t)felts_per_row * 8, &p)) return rc;
+    if (ctx->st_aux2.reserve(n * 32)) return SSA_ERR_HIP;
+    if (int rc = ssa_rescue_hash_many_device(ctx, (const uint64_t *)p, felts_per_row, n,
+                                             (uint64_t *)ctx->st_aux2.p))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(digests_out, ctx->st_aux2.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces,
+                                    const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
+                                    size_t msg_len, size_t n, uint8_t *pks_out, uint8_t *sigs_out) {
+    if (!ctx || (n && (!sks || !nonces || !pks_out || !sigs_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (n == 0) return 0;
+    // PrivateKey::new never yields 0 (src/private.rs:49-57)
+    static const uint8_t q_le[32] = {0xcf, 0xac, 0xd4, 0xae, 0x3e, 0x62, 0x43, 0xd4, 0x22, 0x77, 0x15,
+                                     0x30, 0x23, 0xa7, 0x7a, 0x32, 0xb5, 0x37, 0x0a, 0x99, 0x0f, 0xbf,
+                                     0x3f, 0x56, 0xd0, 0x22, 0x3f, 0x3b, 0x9b, 0x59, 0xf2, 0x7a};
+    for (size_t i = 0; i < n; i++) {
+        bool zero = true, is_q = true;
+        for (int k = 0; k < 32; k++) {
+            zero = zero && sks[32 * i + k] == 0;
+            is_q = is_q && sks[32 * i + k] == q_le[k];
+        }
+        if (zero || is_q) return SSA_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    StagedInputs s;
+    const void *p_sk, *p_nonce;
+    if (int rc = stage_up(ctx, ctx->st_sigs, sks, n * 32, &p_sk)) return rc;
+    if (int rc = stage_up(ctx, ctx->st_pks, nonces, n * 32, &p_nonce)) return rc;
+    if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
+    if (ctx->st_aux.reserve(n * 96) || ctx->st_aux2.reserve(n * 81)) return SSA_ERR_HIP;
+    if (int rc = ssa_keygen_sign_many_device(ctx, (const u8 *)p_sk, (const u8 *)p_nonce, s.msgs, s.off,
+                                             msg_stride, msg_len, n, (u8 *)ctx->st_aux.p,
+                                             (u8 *)ctx->st_aux2.p))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(pks_out, ctx->st_aux.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(sigs_out, ctx->st_aux2.p, n * 81, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ probes
+extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
+                               size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {
+    if (!ctx || !a || !out || n == 0 || op < 0 || op > 6) return SSA_ERR_ARG;
+    if ((op == 0 || op == 3 || op == 4 || op == 5) && !b) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const void *da, *db = nullptr;
+    if (int rc = stage_up(ctx, ctx->st_aux, a, n * a_stride * 8, &da)) return rc;
+    if (b)
+        if (int rc = stage_up(ctx, ctx->st_aux2, b, n * b_stride * 8, &db)) return rc;
+    if (ctx->st_status.reserve(n * out_stride * 8)) return SSA_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(ctx->st_status.p, 0, n * out_stride * 8, ctx->stream));
+    if (op == 4) {
+        if (ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
+        hipLaunchKernelGGL(ssa_k_debug_mul, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const u64 *)da,
+                           (const u64 *)db, n, a_stride, b_stride, (u64 *)ctx->ws_tab.p,
+                           (u64 *)ctx->st_status.p, out_stride);
+    } else {
+        hipLaunchKernelGGL(ssa_k_debug, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, op, (const u64 *)da,
+                           (const u64 *)db, n, a_stride, b_stride, (u64 *)ctx->st_status.p, out_stride);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, ctx->st_status.p, n * out_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int ssa_bench_fpmul(ssa_ctx *ctx, int variant, double *fpmul_per_s) {
+    if (!ctx || !fpmul_per_s) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const unsigned blocks = 256 * 16, threads = 256;
+    const int iters = 2000;
+    if (ctx->st_aux.reserve((size_t)blocks * threads * 8)) return SSA_ERR_HIP;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double muls_per_thread = 0;
+    for (int rep = 0; rep < 2; rep++) {  // first repetition warms up
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+        switch (variant) {
+            case 0:
+                hipLaunchKernelGGL(ssa_k_fpmul_bench<1>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                                   (u64 *)ctx->st_aux.p, 0x1234567ull, iters);
+                muls_per_thread = 2.0 * 1 * iters;
+                break;
+            case 1:
+                hipLaunchKernelGGL(ssa_k_fpmul_bench<4>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                                   (u64 *)ctx->st_aux.p, 0x1234567ull, iters);
+                muls_per_thread = 2.0 * 4 * iters;
+                break;
+            case 2:
+                hipLaunchKernelGGL(ssa_k_fpmul_bench<8>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                                   (u64 *)ctx->st_aux.p, 0x1234567ull, iters);
+                muls_per_thread = 2.0 * 8 * iters;
+                break;
+            default:
+                hipLaunchKernelGGL(ssa_k_f6mul_bench, dim3(blocks), dim3(threads), 0, ctx->stream,
+                                   (u64 *)ctx->st_aux.p, 0x1234567ull, iters / 4);
+                muls_per_thread = (36.0 + 21.0) * (iters / 4);
+                break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+    }
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *fpmul_per_s = muls_per_thread * (double)blocks * threads / (ms * 1e-3);
+    return 0;
+}

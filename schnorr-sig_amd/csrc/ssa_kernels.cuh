@@ -1,0 +1,572 @@
+// HIP kernels of the verification path, one signature per lane (wave64, gfx950).
+//
+//   ssa_k_hash     hash_message (src/signature.rs:274-306) -> challenge scalar h mod q
+//   ssa_k_verify   [h]P + [e]G, x-only compare, optional [q]P == O (src/signature.rs:181-205)
+//   ssa_k_gtable   fixed-base comb table for G (BASEPOINT_TABLE, src/signature.rs:20,116)
+//   ssa_k_sign     keygen + sign (src/public.rs:26-32, src/signature.rs:114-129)
+//   ssa_k_rescue   RescueHash::hash_field on raw felt rows (src/signature.rs:303)
+//
+// HBM layout: inputs stay in the caller's AoS byte records (81-B signatures, 96-B keys,
+// message bytes); per-lane intermediates live in the context workspace:
+//   ws_h    n x 4 u64       challenge scalars
+//   ws_tab  n x 8 x 18 u64  per-lane Jacobian multiples 1P..8P, lane-contiguous so that a lane's
+//                           gather of one entry is nine 16-byte loads from one 144-byte row
+//   gtab    16 x 65536 x 12 u64 affine multiples d*2^(16w)*G (100 MB, Infinity-Cache resident)
+#pragma once
+#include "curve.cuh"
+#include "rescue.cuh"
+
+namespace ssa {
+
+constexpr int GW_BITS = 16;
+constexpr int GW_COUNT = 16;
+constexpr size_t GTAB_ENTRIES = (size_t)GW_COUNT << GW_BITS;
+constexpr int PTAB_ENTRIES = 8;
+constexpr int PTAB_ENTRY_U64 = 18;
+
+constexpr u32 ST_OK = 0, ST_INVALID_PK = 1, ST_INVALID_SIG = 2, ST_MALFORMED = 3;
+
+typedef uint8_t u8;
+
+SSA_DEV u64 ld_u64_le(const u8 *p) {
+    u64 v = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; k--) v = (v << 8) | p[k];
+    return v;
+}
+SSA_DEV void st_u64_le(u8 *p, u64 v) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) p[k] = (u8)(v >> (8 * k));
+}
+// six limbs; ok &= all canonical
+SSA_DEV fp6 ld_fp6(const u8 *p, bool &ok) {
+    fp6 r;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        r.c[i] = ld_u64_le(p + 8 * i);
+        ok = ok && (r.c[i] < FP_P);
+    }
+    return r;
+}
+SSA_DEV void st_fp6(u8 *p, const fp6 &a) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) st_u64_le(p + 8 * i, fp_canon(a.c[i]));
+}
+SSA_DEV sc256 ld_sc(const u8 *p) {
+    sc256 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.w[i] = ld_u64_le(p + 8 * i);
+    return r;
+}
+
+struct MsgView {
+    const u8 *msgs;
+    const u64 *off;  // n+1 offsets or nullptr
+    size_t stride, len;
+};
+SSA_DEV const u8 *msg_ptr(const MsgView &mv, size_t i, u32 &len) {
+    if (mv.off) {
+        u64 b = mv.off[i];
+        len = (u32)(mv.off[i + 1] - b);
+        return mv.msgs + b;
+    }
+    len = (u32)mv.len;
+    return mv.msgs + i * mv.stride;
+}
+
+// message felt c (src/signature.rs:285-301): 7 bytes LE; the final partial chunk gets a 0x01
+// terminator at index chunk_len; no terminator felt when len % 7 == 0.
+SSA_DEV u64 msg_felt(const u8 *m, u32 len, u32 c) {
+    const u32 off = 7u * c;
+    const u32 rem = len - off;
+    u64 v = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        u64 b = 0;
+        if ((u32)k < rem) b = m[off + k];
+        else if ((u32)k == rem) b = 1;
+        v |= b << (8 * k);
+    }
+    return v;
+}
+
+// hash_message for lane data already in registers -> 4 canonical digest felts
+SSA_DEV void hash_message_lane(u64 *A, u64 *B, const DevParams *__restrict__ prm, const fp6 &rx,
+                               const fp6 &px, u64 py0, const u8 *m, u32 len, u64 (&digest)[4]) {
+    const u32 nmsg = (len + 6u) / 7u;
+    const u32 n_felts = 13u + nmsg;
+    auto src = [&](u32 idx) -> u64 {
+        u64 v;
+        if (idx < 13u) {
+            v = py0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                if (idx == (u32)i) v = rx.c[i];
+                if (idx == (u32)(6 + i)) v = px.c[i];
+            }
+        } else {
+            v = msg_felt(m, len, idx - 13u);
+        }
+        return v;
+    };
+    sponge_hash(A, B, prm, n_felts, src, digest);
+}
+
+// ------------------------------------------------------------------------------------------
+#ifndef SSA_HOST_TEST
+__global__ void __launch_bounds__(256)
+ssa_k_hash(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs,
+           const u8 *__restrict__ pks, MsgView mv, size_t n, u64 *__restrict__ h_out,
+           u8 *__restrict__ digest_out) {
+    __shared__ u64 lds[RS_LDS_U64];
+    u64 *A = lds + threadIdx.x, *B = A + 12 * RS_STRIDE;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool ok = true;
+    const fp6 rx = ld_fp6(sigs + 81 * i, ok);
+    const fp6 px = ld_fp6(pks + 96 * i, ok);
+    const u64 py0 = ld_u64_le(pks + 96 * i + 48);
+    u32 len;
+    const u8 *m = msg_ptr(mv, i, len);
+    u64 d[4];
+    hash_message_lane(A, B, prm, rx, px, py0, m, len, d);
+    if (digest_out) {  // Digest::to_bytes, src/signature.rs:305
+#pragma unroll
+        for (int k = 0; k < 4; k++) st_u64_le(digest_out + 32 * i + 8 * k, d[k]);
+    }
+    if (h_out) {       // Scalar::from_bits_vartime, src/signature.rs:189-192
+        sc256 h;
+#pragma unroll
+        for (int k = 0; k < 4; k++) h.w[k] = d[k];
+        h = sc_reduce256(h);
+#pragma unroll
+        for (int k = 0; k < 4; k++) h_out[4 * i + k] = h.w[k];
+    }
+}
+#endif  // SSA_HOST_TEST
+
+#ifndef SSA_HOST_TEST
+__global__ void __launch_bounds__(256)
+ssa_k_rescue(const DevParams *__restrict__ prm, const u64 *__restrict__ felts, u32 per_row,
+             size_t n, u64 *__restrict__ out) {
+    __shared__ u64 lds[RS_LDS_U64];
+    u64 *A = lds + threadIdx.x, *B = A + 12 * RS_STRIDE;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 *row = felts + (size_t)per_row * i;
+    u64 d[4];
+    sponge_hash(A, B, prm, per_row, [&](u32 idx) -> u64 { return row[idx]; }, d);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * i + k] = d[k];
+}
+#endif  // SSA_HOST_TEST
+
+// ------------------------------------------------------------------------------------------
+// per-lane table rows
+SSA_DEV void st_jac(u64 *__restrict__ row, const jac &p) {
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(row);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        q[i] = make_ulonglong2(p.X.c[2 * i], p.X.c[2 * i + 1]);
+        q[3 + i] = make_ulonglong2(p.Y.c[2 * i], p.Y.c[2 * i + 1]);
+        q[6 + i] = make_ulonglong2(p.Z.c[2 * i], p.Z.c[2 * i + 1]);
+    }
+}
+SSA_DEV jac ld_jac(const u64 *__restrict__ row) {
+    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(row);
+    jac p;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ulonglong2 a = q[i], b = q[3 + i], c = q[6 + i];
+        p.X.c[2 * i] = a.x; p.X.c[2 * i + 1] = a.y;
+        p.Y.c[2 * i] = b.x; p.Y.c[2 * i + 1] = b.y;
+        p.Z.c[2 * i] = c.x; p.Z.c[2 * i + 1] = c.y;
+    }
+    return p;
+}
+SSA_DEV aff ld_aff(const u64 *__restrict__ row) {
+    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(row);
+    aff p;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ulonglong2 a = q[i], b = q[3 + i];
+        p.x.c[2 * i] = a.x; p.x.c[2 * i + 1] = a.y;
+        p.y.c[2 * i] = b.x; p.y.c[2 * i + 1] = b.y;
+    }
+    return p;
+}
+
+// multiples 1P..8P of a lane's point into its table row block
+SSA_DEV void build_ptab(u64 *__restrict__ tab, const jac &p) {
+    st_jac(tab, p);
+    jac p2 = jac_dbl(p);
+    st_jac(tab + PTAB_ENTRY_U64, p2);
+    jac acc = p2;
+#pragma unroll 1
+    for (int e = 2; e < PTAB_ENTRIES; e++) {  // 3P .. 8P by repeated addition of P
+        acc = jac_add(acc, p);
+        st_jac(tab + e * PTAB_ENTRY_U64, acc);
+    }
+}
+
+// [k]P from the lane's table with signed 4-bit windows (offset recoding): 64 x (4 dbl + add)
+SSA_FN jac mul_ptab(const u64 *__restrict__ tab, sc256 k) {
+    u32 top;
+    const sc256 kr = sc_recode_offset(k, top);
+    jac acc = jac_identity();
+    if (top) acc = ld_jac(tab);
+#pragma unroll 1
+    for (int w = 63; w >= 0; w--) {
+#pragma unroll 1
+        for (int d = 0; d < 4; d++) acc = jac_dbl(acc);
+        const int digit = (int)sc_nibble(kr, (u32)w) - 8;
+        if (digit != 0) {
+            const int mag = digit < 0 ? -digit : digit;
+            jac q = ld_jac(tab + (mag - 1) * PTAB_ENTRY_U64);
+            q = jac_neg_if(q, digit < 0);
+            acc = jac_add(acc, q);
+        }
+    }
+    return acc;
+}
+
+// acc += [e]G from the comb table: one mixed addition per non-zero 16-bit window
+SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e) {
+#pragma unroll 1
+    for (int w = 0; w < GW_COUNT; w++) {
+        const u32 d = sc_win16(e, (u32)w);
+        if (d != 0) {
+            const aff q = ld_aff(gtab + (((size_t)w << GW_BITS) + d) * 12);
+            acc = jac_madd(acc, q);
+        }
+    }
+    return acc;
+}
+
+#ifndef SSA_HOST_TEST
+__global__ void __launch_bounds__(256, 2)
+ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
+             const u8 *__restrict__ pk_inf, const u64 *__restrict__ h_in,
+             const u64 *__restrict__ gtab, u64 *__restrict__ ws_tab, size_t n, u32 flags,
+             u8 *__restrict__ status_out, unsigned long long *__restrict__ n_fail) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 status = ST_OK;
+    if (i < n) {
+        bool ok = true;
+        const fp6 xs = ld_fp6(sigs + 81 * i, ok);           // Fp6::from_bytes(..).unwrap(), :186
+        const sc256 e = ld_sc(sigs + 81 * i + 49);
+        ok = ok && !sc_geq_q(e);
+        aff P;
+        P.x = ld_fp6(pks + 96 * i, ok);
+        P.y = ld_fp6(pks + 96 * i + 48, ok);
+        const bool inf = pk_inf && pk_inf[i];
+        if (ok && !inf) ok = aff_on_curve(P);
+        if (!ok) {
+            status = ST_MALFORMED;
+        } else {
+            u64 *tab = ws_tab + i * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64);
+            jac pj = jac_from_aff(P);
+            if (inf) pj = jac_identity();
+            build_ptab(tab, pj);
+            if (flags & 1u) {                               // is_torsion_free, :182-184
+                sc256 q;
+#pragma unroll
+                for (int k = 0; k < 4; k++) q.w[k] = SC_Q(k);
+                const jac t = mul_ptab(tab, q);
+                if (!jac_is_identity(t)) status = ST_INVALID_PK;
+            }
+            if (status == ST_OK) {
+                sc256 h;
+#pragma unroll
+                for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
+                jac r = mul_ptab(tab, h);                   // [h]P
+                r = add_base_mul(r, gtab, e);               // + [e]G, :196-198
+                // r.get_x() == x_felt (:200): X == x * Z^2; the identity's x is taken as 0
+                bool eq;
+                if (jac_is_identity(r))
+                    eq = f6_is_zero(xs);
+                else
+                    eq = f6_eq(r.X, f6_mul(xs, f6_sqr(r.Z)));
+                status = eq ? ST_OK : ST_INVALID_SIG;
+            }
+        }
+        status_out[i] = (u8)status;
+    }
+    // aggregate verdict: one ballot + one atomic per wave
+    const unsigned long long bad = __ballot(status != ST_OK);
+    if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(n_fail, (unsigned long long)__popcll(bad));
+}
+#endif  // SSA_HOST_TEST
+
+// ------------------------------------------------------------------------------------------
+// gtab[w][d] = affine [d * 2^(16 w)] G, d = 1..65535 (d = 0 rows stay zero and are never read)
+#ifndef SSA_HOST_TEST
+__global__ void __launch_bounds__(256)
+ssa_k_gtable(const DevParams *__restrict__ prm, u64 *__restrict__ gtab) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= GTAB_ENTRIES) return;
+    const u32 w = (u32)(t >> GW_BITS), d = (u32)(t & ((1u << GW_BITS) - 1u));
+    aff g;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        g.x.c[i] = prm->gen_x[i];
+        g.y.c[i] = prm->gen_y[i];
+    }
+    jac acc = jac_identity();
+#pragma unroll 1
+    for (int b = GW_BITS - 1; b >= 0; b--) {
+        acc = jac_dbl(acc);
+        if ((d >> b) & 1u) acc = jac_madd(acc, g);
+    }
+#pragma unroll 1
+    for (u32 s = 0; s < w * GW_BITS; s++) acc = jac_dbl(acc);
+    const aff a = jac_to_aff(acc);
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(gtab + t * 12);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        q[i] = make_ulonglong2(a.x.c[2 * i], a.x.c[2 * i + 1]);
+        q[3 + i] = make_ulonglong2(a.y.c[2 * i], a.y.c[2 * i + 1]);
+    }
+}
+#endif  // SSA_HOST_TEST
+
+// ------------------------------------------------------------------------------------------
+// scalar arithmetic mod q for signing (e = r - sk*h, src/signature.rs:124)
+SSA_DEV sc256 sc_dbl_mod(const sc256 &a) {  // 2a mod q, a < q < 2^255
+    sc256 r;
+    r.w[3] = (a.w[3] << 1) | (a.w[2] >> 63);
+    r.w[2] = (a.w[2] << 1) | (a.w[1] >> 63);
+    r.w[1] = (a.w[1] << 1) | (a.w[0] >> 63);
+    r.w[0] = a.w[0] << 1;
+    if (sc_geq_q(r)) r = sc_sub_q(r);
+    return r;
+}
+SSA_DEV sc256 sc_add_mod(const sc256 &a, const sc256 &b) {
+    sc256 r;
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 s = a.w[i] + b.w[i];
+        u64 c1 = s < a.w[i];
+        u64 s2 = s + carry;
+        u64 c2 = s2 < s;
+        r.w[i] = s2;
+        carry = c1 | c2;
+    }
+    if (sc_geq_q(r)) r = sc_sub_q(r);
+    return r;
+}
+SSA_DEV sc256 sc_neg_mod(const sc256 &a) {  // q - a (a < q), 0 stays 0
+    sc256 r;
+    u64 borrow = 0;
+    bool zero = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 d = SC_Q(i) - a.w[i];
+        u64 b1 = SC_Q(i) < a.w[i];
+        u64 d2 = d - borrow;
+        u64 b2 = d < borrow;
+        r.w[i] = d2;
+        borrow = b1 | b2;
+        zero = zero && a.w[i] == 0;
+    }
+    if (zero) r = a;
+    return r;
+}
+// a*b mod q by double-and-add over the bits of b (signing only; not on the verify path)
+SSA_DEV sc256 sc_mul_mod(const sc256 &a, const sc256 &b) {
+    sc256 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.w[i] = 0;
+#pragma unroll 1
+    for (int bit = 255; bit >= 0; bit--) {
+        r = sc_dbl_mod(r);
+        const u32 wi = (u32)bit >> 6;
+        u64 word = b.w[0];
+        if (wi == 1) word = b.w[1];
+        if (wi == 2) word = b.w[2];
+        if (wi == 3) word = b.w[3];
+        if ((word >> (bit & 63)) & 1ull) r = sc_add_mod(r, a);
+    }
+    return r;
+}
+
+#ifndef SSA_HOST_TEST
+__global__ void __launch_bounds__(256)
+ssa_k_sign(const DevParams *__restrict__ prm, const u64 *__restrict__ gtab,
+           const u8 *__restrict__ sks, const u8 *__restrict__ nonces, MsgView mv, size_t n,
+           u8 *__restrict__ pks_out, u8 *__restrict__ sigs_out) {
+    __shared__ u64 lds[RS_LDS_U64];
+    u64 *A = lds + threadIdx.x, *B = A + 12 * RS_STRIDE;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const sc256 sk = sc_reduce256(ld_sc(sks + 32 * i));
+    const sc256 r = sc_reduce256(ld_sc(nonces + 32 * i));
+    const aff pk = jac_to_aff(add_base_mul(jac_identity(), gtab, sk));   // src/public.rs:29
+    const jac rj = add_base_mul(jac_identity(), gtab, r);                // src/signature.rs:116
+    const aff rp = jac_to_aff(rj);
+    st_fp6(pks_out + 96 * i, pk.x);
+    st_fp6(pks_out + 96 * i + 48, pk.y);
+    u32 len;
+    const u8 *m = msg_ptr(mv, i, len);
+    u64 d[4];
+    hash_message_lane(A, B, prm, rp.x, pk.x, pk.y.c[0], m, len, d);            // :118
+    sc256 h;
+#pragma unroll
+    for (int k = 0; k < 4; k++) h.w[k] = d[k];
+    h = sc_reduce256(h);                                                 // :122
+    const sc256 e = sc_add_mod(r, sc_neg_mod(sc_mul_mod(sk, h)));        // :124
+    u8 *sig = sigs_out + 81 * i;
+    st_fp6(sig, rp.x);
+    // CompressedPoint flag byte: bit 7 = infinity (src/public.rs:95-101); bit 6 = y is the
+    // lexicographically larger root (unpinned; ignored by verify)
+    const fp6 yn = f6_canon(f6_neg(rp.y));
+    bool larger = false, decided = false;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if (!decided && rp.y.c[k] != yn.c[k]) {
+            larger = rp.y.c[k] > yn.c[k];
+            decided = true;
+        }
+    }
+    sig[48] = jac_is_identity(rj) ? 0x80 : (larger ? 0x40 : 0x00);
+#pragma unroll
+    for (int k = 0; k < 4; k++) st_u64_le(sig + 49 + 8 * k, e.w[k]);
+}
+#endif  // SSA_HOST_TEST
+
+// ------------------------------------------------------------------------------------------
+// arithmetic probes (ssa_debug_arith)
+#ifndef SSA_HOST_TEST
+__global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
+                            size_t as, size_t bs, u64 *__restrict__ out, size_t os) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 *pa = a + i * as, *pb = b ? b + i * bs : nullptr;
+    u64 *po = out + i * os;
+    if (op == 5) {
+        po[0] = fp_canon(fp_mul(pa[0], pb[0]));
+        return;
+    }
+    if (op == 6) {
+        po[0] = fp_canon(fp_inv(pa[0]));
+        return;
+    }
+    if (op <= 2) {
+        fp6 x, y, r;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            x.c[k] = pa[k];
+            y.c[k] = pb ? pb[k] : 0;
+        }
+        if (op == 0) r = f6_mul(x, y);
+        else if (op == 1) r = f6_sqr(x);
+        else r = f6_inv(x);
+        r = f6_canon(r);
+#pragma unroll
+        for (int k = 0; k < 6; k++) po[k] = r.c[k];
+        return;
+    }
+    if (op == 3) {  // affine + affine (a[12] = inf flag, b[12] = inf flag) -> 12 felts + inf
+        aff p, q;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            p.x.c[k] = pa[k]; p.y.c[k] = pa[6 + k];
+            q.x.c[k] = pb[k]; q.y.c[k] = pb[6 + k];
+        }
+        jac pj = pa[12] ? jac_identity() : jac_from_aff(p);
+        jac r;
+        if (pb[12]) r = pj;
+        else if (pa[13]) r = jac_add(pj, jac_from_aff(q));  // a[13] selects the general add
+        else r = jac_madd(pj, q);
+        const aff o = jac_to_aff(r);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            po[k] = o.x.c[k];
+            po[6 + k] = o.y.c[k];
+        }
+        po[12] = jac_is_identity(r) ? 1 : 0;
+        return;
+    }
+}
+#endif  // SSA_HOST_TEST
+
+// [k]P with the production table code path (op 4): a = k (4 u64), b = P (12 u64 + inf)
+#ifndef SSA_HOST_TEST
+__global__ void ssa_k_debug_mul(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
+                                size_t as, size_t bs, u64 *__restrict__ ws_tab,
+                                u64 *__restrict__ out, size_t os) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 *pa = a + i * as, *pb = b + i * bs;
+    u64 *po = out + i * os;
+    sc256 k;
+#pragma unroll
+    for (int j = 0; j < 4; j++) k.w[j] = pa[j];
+    aff p;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        p.x.c[j] = pb[j];
+        p.y.c[j] = pb[6 + j];
+    }
+    u64 *tab = ws_tab + i * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64);
+    build_ptab(tab, pb[12] ? jac_identity() : jac_from_aff(p));
+    const jac r = mul_ptab(tab, k);
+    const aff o = jac_to_aff(r);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        po[j] = o.x.c[j];
+        po[6 + j] = o.y.c[j];
+    }
+    po[12] = jac_is_identity(r) ? 1 : 0;
+}
+#endif  // SSA_HOST_TEST
+
+// register-resident Fp-mul throughput probe: each lane runs ILP independent multiply chains
+#ifndef SSA_HOST_TEST
+template <int ILP>
+__global__ void __launch_bounds__(256) ssa_k_fpmul_bench(u64 *out, u64 seed, int iters) {
+    u64 x[ILP], y[ILP];
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) {
+        x[j] = seed * (t + 1) + 0x9e3779b97f4a7c15ULL * (j + 1);
+        y[j] = seed ^ (t * 0xbf58476d1ce4e5b9ULL + j);
+    }
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < ILP; j++) x[j] = fp_mul(x[j], y[j]);
+#pragma unroll
+        for (int j = 0; j < ILP; j++) y[j] = fp_mul(y[j], x[j]);
+    }
+    u64 acc = 0;
+#pragma unroll
+    for (int j = 0; j < ILP; j++) acc ^= x[j] ^ y[j];
+    out[t] = acc;
+}
+#endif  // SSA_HOST_TEST
+
+// same probe through the lazy Fp6 product (36 products + 6 reductions per f6_mul)
+#ifndef SSA_HOST_TEST
+__global__ void __launch_bounds__(256) ssa_k_f6mul_bench(u64 *out, u64 seed, int iters) {
+    fp6 x, y;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        x.c[j] = seed * (t + 1) + 0x9e3779b97f4a7c15ULL * (j + 1);
+        y.c[j] = seed ^ (t * 0xbf58476d1ce4e5b9ULL + j);
+    }
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+        x = f6_mul(x, y);
+        y = f6_sqr(x);
+    }
+    u64 acc = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) acc ^= x.c[j] ^ y.c[j];
+    out[t] = acc;
+}
+#endif  // SSA_HOST_TEST
+
+}  // namespace ssa

@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact everywhere (integer arithmetic)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 2**64 - 2**32 + 1
+Q = 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
+EDGE = [0, 1, P - 1, 2**32 - 1, 2**32, P - 2**32, 2**63, P - 2, 7, 2**32 + 1]
+
+
+def rand_felts(rng, shape):
+    v = rng.integers(0, 2**64, size=shape, dtype=np.uint64)
+    return np.where(v >= np.uint64(P), v - np.uint64(P), v)
+
+
+def make_scalars(rng, n):
+    s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    s[:, 31] &= 0x3F          # < 2^254 < q, non-zero with overwhelming probability
+    s[:, 0] |= 1
+    return s
+
+
+# ---------------------------------------------------------------- arithmetic probes
+def test_fp_mul_and_inv(engine):
+    rng = np.random.default_rng(1)
+    a = np.concatenate([np.array(EDGE, dtype=np.uint64).repeat(len(EDGE)), rand_felts(rng, 4096)])
+    b = np.concatenate([np.tile(np.array(EDGE, dtype=np.uint64), len(EDGE)), rand_felts(rng, 4096)])
+    got = engine.debug_arith(5, a.reshape(-1, 1), b.reshape(-1, 1), 1)[:, 0]
+    want = np.array([int(x) * int(y) % P for x, y in zip(a, b)], dtype=np.uint64)
+    assert (got == want).all()
+    # loose (non-canonical) inputs are legal inside the kernels
+    loose = np.array([2**64 - 1, P, P + 5, 2**64 - 2**31], dtype=np.uint64)
+    got = engine.debug_arith(5, loose.reshape(-1, 1), loose[::-1].copy().reshape(-1, 1), 1)[:, 0]
+    want = np.array([int(x) * int(y) % P for x, y in zip(loose, loose[::-1])], dtype=np.uint64)
+    assert (got == want).all()
+    nz = a[a != 0]
+    got = engine.debug_arith(6, nz.reshape(-1, 1), None, 1)[:, 0]
+    want = np.array([pow(int(x), P - 2, P) for x in nz], dtype=np.uint64)
+    assert (got == want).all()
+
+
+def test_fp6_ops(engine, oracle):
+    rng = np.random.default_rng(2)
+    n = 512
+    a = rand_felts(rng, (n, 6))
+    b = rand_felts(rng, (n, 6))
+    # edge rows: all-(p-1), sparse, zero
+    a[0] = P - 1; b[0] = P - 1
+    a[1] = 0; a[2] = [1, 0, 0, 0, 0, 0]; a[3] = [0, 0, 0, 0, 0, P - 1]; b[3] = [0, 0, 0, 0, 0, P - 1]
+    got = engine.debug_arith(0, a, b, 6)
+    want = np.stack([oracle.fp6_mul(a[i], b[i]) for i in range(n)])
+    assert (got == want).all()
+    got = engine.debug_arith(1, a, None, 6)
+    want = np.stack([oracle.fp6_sqr(a[i]) for i in range(n)])
+    assert (got == want).all()
+    nz = a[np.any(a != 0, axis=1)][:128]
+    got = engine.debug_arith(2, nz, None, 6)
+    want = np.stack([oracle.fp6_inv(nz[i]) for i in range(nz.shape[0])])
+    assert (got == want).all()
+
+
+def _aff_rows(pts):
+    rows = np.zeros((len(pts), 14), dtype=np.uint64)
+    for i, p in enumerate(pts):
+        if p is None:
+            rows[i, 12] = 1
+        else:
+            rows[i, :6] = p[0]
+            rows[i, 6:12] = p[1]
+    return rows
+
+
+def test_point_add_exceptional_cases(engine, oracle):
+    """P+Q generic, P+P (doubling inside add), P+(-P) (identity), identity operands, and the
+    order-2-ish fixture point: every branch of jac_madd / jac_add."""
+    import pymodel as m
+    g = m.default_params().generator()
+    p2 = m.pt_mul(2, g)
+    p3 = m.pt_mul(3, g)
+    f = m.FIXTURE_SMALL_ORDER_PK
+    cases = [(g, p2), (g, g), (g, m.pt_neg(g)), (None, g), (g, None), (p3, p2), (f, f), (f, m.pt_neg(f)),
+             (f, g), (None, None)]
+    for general in (0, 1):
+        a = _aff_rows([c[0] for c in cases])
+        b = _aff_rows([c[1] for c in cases])
+        a[:, 13] = general
+        got = engine.debug_arith(3, a, b, 13)
+        for i, (x, y) in enumerate(cases):
+            want = m.pt_add(x, y)
+            if want is None:
+                assert got[i, 12] == 1, (general, i)
+            else:
+                assert got[i, 12] == 0, (general, i)
+                assert tuple(int(v) for v in got[i, :6]) == want[0], (general, i)
+                assert tuple(int(v) for v in got[i, 6:12]) == want[1], (general, i)
+
+
+def test_scalar_mul_table_path(engine, oracle):
+    import pymodel as m
+    rng = np.random.default_rng(3)
+    g = m.default_params().generator()
+    f = m.FIXTURE_SMALL_ORDER_PK
+    ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, Q - 1, Q, Q + 1, 2**255 - 1, 2**256 - 1, 0x8888888888888888,
+          int("8" * 64, 16), int("7" * 64, 16), int("f" * 63, 16)]
+    ks += [int.from_bytes(rng.bytes(32), "little") for _ in range(46)]
+    pts = [g] * len(ks) + [f] * 8 + [None] * 2
+    ks = ks + [Q, 5, 2 * Q // 5, Q // 5, 2, 3, 1, 0] + [5, 0]
+    a = np.zeros((len(ks), 4), dtype=np.uint64)
+    for i, k in enumerate(ks):
+        a[i] = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint64)
+    b = _aff_rows(pts)[:, :13].copy()
+    got = engine.debug_arith(4, a, b, 13)
+    for i, (k, p) in enumerate(zip(ks, pts)):
+        want = oracle.point_mul(k, p)
+        if want is None:
+            assert got[i, 12] == 1, i
+        else:
+            assert got[i, 12] == 0, i
+            assert tuple(int(v) for v in got[i, :6]) == want[0], i
+            assert tuple(int(v) for v in got[i, 6:12]) == want[1], i
+
+
+# ---------------------------------------------------------------- Rescue (config 2)
+def test_rescue_hash_config2(engine, oracle):
+    """2^16 rows of 25 felts incl. an edge-value slab; the oracle
+    checks a strided sample of 2048 rows plus the whole edge slab."""
+    rng = np.random.default_rng(0x5C4E0221)
+    n = 1 << 16
+    felts = rand_felts(rng, (n, 25))
+    edge = np.array([0, 1, P - 1, 2**32 - 1, 2**32, P - 2**32], dtype=np.uint64)
+    for r in range(64):
+        felts[r] = np.roll(np.resize(edge, 25), r)
+    got = engine.rescue_hash_many(felts)
+    idx = np.concatenate([np.arange(64), np.arange(64, n, 32)])
+    want = oracle.hash_field_many(felts[idx])
+    assert (got[idx] == want).all()
+    assert (got < np.uint64(P)).all()
+
+
+@pytest.mark.parametrize("width", [0, 1, 7, 8, 9, 16, 17, 24])
+def test_rescue_hash_ragged_widths(engine, oracle, width):
+    rng = np.random.default_rng(width)
+    felts = rand_felts(rng, (300, width)) if width else np.zeros((300, 0), dtype=np.uint64)
+    got = engine.rescue_hash_many(felts)
+    want = oracle.hash_field_many(felts) if width else np.stack([oracle.hash_field(np.zeros(0, np.uint64))] * 300)
+    assert (got == want).all()
+
+
+# ---------------------------------------------------------------- sign / hash_message / verify
+@pytest.mark.parametrize("msg_len", [0, 1, 6, 7, 8, 13, 14, 24, 48, 80, 160])
+def test_sign_hash_verify_message_lengths(engine, oracle, msg_len):
+    rng = np.random.default_rng(100 + msg_len)
+    n = 96
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, msg_len), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    pks_o, sigs_o = oracle.keygen_sign_many(sks, nonces, msgs)
+    assert (pks == pks_o).all()
+    assert (sigs == sigs_o).all()
+    dig = engine.hash_message_many(sigs, pks, msgs)
+    for i in range(0, n, 7):
+        assert dig[i].tobytes() == oracle.hash_message(sigs[i, :48].tobytes(), pks[i].tobytes(), msgs[i].tobytes())
+    for torsion in (False, True):
+        st, nf = engine.verify_many(sigs, pks, msgs, check_torsion=torsion)
+        assert nf == 0 and (st == 0).all()
+
+
+def corrupt(rng, sigs, pks, msgs, frac=0.25):
+    """config-5 style corruptions; returns the corrupted copies."""
+    import pymodel as m
+    sigs, pks, msgs = sigs.copy(), pks.copy(), msgs.copy()
+    n = sigs.shape[0]
+    idx = rng.permutation(n)[: max(5, int(n * frac))]
+    f = m.FIXTURE_SMALL_ORDER_PK
+    fbytes = np.frombuffer(m.fp6_to_bytes48(f[0]) + m.fp6_to_bytes48(f[1]), dtype=np.uint8)
+    for k, i in enumerate(idx):
+        kind = k % 5
+        if kind == 0:
+            sigs[i, 49] ^= 1                       # flip bit 0 of e (stays < q: top byte untouched)
+        elif kind == 1 and msgs.shape[1] > 0:
+            msgs[i, msgs.shape[1] // 2] ^= 0x10    # flip one message bit
+        elif kind == 2:
+            pks[i] = pks[(i + 1) % n]              # someone else's key
+        elif kind == 3:
+            sigs[i, :49] = sigs[(i + 1) % n, :49]  # someone else's R.x (on curve, canonical)
+        else:
+            pks[i] = fbytes                        # non-subgroup fixture key
+    return sigs, pks, msgs, idx
+
+
+def test_verify_corrupted_batch_vs_oracle(engine, oracle):
+    rng = np.random.default_rng(0x5C4E0225)
+    n = 1024
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, 80), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    sigs, pks, msgs, idx = corrupt(rng, sigs, pks, msgs)
+    for torsion in (True, False):
+        st, nf = engine.verify_many(sigs, pks, msgs, check_torsion=torsion)
+        want = oracle.verify_many(sigs, pks, msgs, check_torsion=torsion)
+        assert (st == want).all()
+        assert nf == int((want != 0).sum())
+        if torsion:   # every fixture key still in place -> InvalidPublicKey (checked first, :182)
+            assert (st[idx[4::5]] == 1).all()
+        else:         # batch semantics never return InvalidPublicKey (src/batch.rs)
+            assert (st != 1).all()
+
+
+def test_verify_malformed_and_edge_inputs(engine, oracle):
+    rng = np.random.default_rng(9)
+    n = 64
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, 24), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    sigs[0, 0:8] = 0xFF                 # limb >= p            -> malformed (reference panics)
+    sigs[1, 49:81] = 0xFF               # e >= q               -> malformed
+    pks[2, 8:16] = 0xFF                 # pk limb >= p         -> malformed
+    sigs[3, :48] = 0; sigs[3, 48] = 0x80  # x = identity encoding -> InvalidSignature (src/signature.rs:408-417)
+    sigs[4, 49:81] = 0                  # e = 0                -> InvalidSignature (:419-425)
+    pks[5, 48] ^= 1                     # pk off the curve     -> malformed (documented divergence)
+    st, nf = engine.verify_many(sigs, pks, msgs, check_torsion=True)
+    assert list(st[:6]) == [3, 3, 3, 2, 2, 3]
+    assert (st[6:] == 0).all() and nf == 6
+    # oracle agrees on everything it defines (rows 0-4)
+    want = oracle.verify_many(sigs, pks, msgs, check_torsion=True)
+    assert (st[:5] == want[:5]).all() and (st[6:] == want[6:]).all()
+
+
+def test_adversarial_e_hits_table_point(engine, oracle):
+    """pk = [k]G known to the attacker, e chosen so that [h]P + [e]G lands exactly on / opposite to
+    comb-table points mid-accumulation: exercises P == +-Q inside jac_madd on real verify inputs."""
+    import pymodel as m
+    prm = m.default_params()
+    g = prm.generator()
+    msg = b"adversarial"
+    cases = []
+    for k in (1, 2, 65536, Q - 1):
+        pk = m.pt_mul(k, g)
+        pk96 = m.fp6_to_bytes48(pk[0]) + m.fp6_to_bytes48(pk[1])
+        rx = m.pt_mul(12345, g)[0]
+        h = m.scalar_from_digest(m.hash_message(rx, pk, msg, prm))
+        for target in (0, 1, 2, 65536, 65537, Q - 1, Q - 65536):
+            e = (target - h * k) % Q          # [h]P + [e]G = [target]G
+            sig = m.fp6_to_bytes48(rx) + b"\0" + e.to_bytes(32, "little")
+            cases.append((sig, pk96))
+    sigs = np.frombuffer(b"".join(c[0] for c in cases), dtype=np.uint8).reshape(-1, 81)
+    pks = np.frombuffer(b"".join(c[1] for c in cases), dtype=np.uint8).reshape(-1, 96)
+    msgs = np.tile(np.frombuffer(msg, dtype=np.uint8), (len(cases), 1))
+    st, _ = engine.verify_many(sigs, pks, msgs, check_torsion=True)
+    want = oracle.verify_many(sigs, pks, msgs, check_torsion=True)
+    assert (st == want).all()
+
+
+def test_identity_public_key(engine, oracle):
+    """sk = 0 is not constructible through PrivateKey::new, but PublicKey(identity) exists
+    (src/public.rs:95-101); with pk = O a signature with e = r verifies."""
+    rng = np.random.default_rng(11)
+    nonces = make_scalars(rng, 4)
+    msgs = rng.integers(0, 256, size=(4, 16), dtype=np.uint8)
+    # R = [r]G via keygen (pk output of keygen with sk = r)
+    rpk, _ = engine.keygen_sign_many(nonces, nonces, msgs)
+    pks = np.zeros((4, 96), dtype=np.uint8)
+    sigs = np.zeros((4, 81), dtype=np.uint8)
+    sigs[:, :48] = rpk[:, :48]
+    sigs[:, 49:] = nonces
+    inf = np.ones(4, dtype=np.uint8)
+    st, nf = engine.verify_many(sigs, pks, msgs, check_torsion=True, pk_inf=inf)
+    want = oracle.verify_many(sigs, pks, msgs, check_torsion=True, pk_inf=inf)
+    assert (st == want).all() and (st == 0).all() and nf == 0
+
+
+def test_variable_length_messages_offsets(engine, oracle):
+    rng = np.random.default_rng(12)
+    lens = [0, 1, 6, 7, 8, 13, 14, 24, 48, 80, 160, 3, 29, 70, 77, 200]
+    n = len(lens)
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    flat = rng.integers(0, 256, size=int(off[-1]) + 1, dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, flat, offsets=off)
+    pks_o, sigs_o = oracle.keygen_sign_many(sks, nonces, flat, offsets=off)
+    assert (pks == pks_o).all() and (sigs == sigs_o).all()
+    st, nf = engine.verify_many(sigs, pks, flat, offsets=off, check_torsion=True)
+    assert nf == 0 and (st == 0).all()
+    flat2 = flat.copy()
+    flat2[int(off[9])] ^= 1
+    st, nf = engine.verify_many(sigs, pks, flat2, offsets=off, check_torsion=True)
+    assert nf == 1 and st[9] == 2
+
+
+def test_empty_batch_and_batch_verdict(engine):
+    import schnorr_sig_amd as ssa
+    assert engine.verify_batch_status(np.zeros((0, 81), np.uint8), np.zeros((0, 96), np.uint8),
+                                      np.zeros((0, 8), np.uint8)) == ssa.OK
+    st, nf = engine.verify_many(np.zeros((0, 81), np.uint8), np.zeros((0, 96), np.uint8),
+                                np.zeros((0, 8), np.uint8))
+    assert st.size == 0 and nf == 0
