@@ -1,0 +1,153 @@
+// schnorr_sig.hpp -- C++17 host-side mirror of the reference's Rust API over the C ABI
+// (include/schnorr_sig_amd.h).  Rust is not available in this image; this header keeps the
+// reference's names, argument meaning and error behaviour so that a Rust `-sys` shim (see
+// INTEGRATION.md) and these classes are interchangeable callers of the same entry points.
+//
+//   schnorr_sig::Signature::verify          <- src/signature.rs:181-205
+//   schnorr_sig::KeyPair::{create, sign, verify_signature}  <- src/keypair.rs:57-65, src/signature.rs:114-165
+//   schnorr_sig::PublicKey::verify_signature <- src/signature.rs:170-176
+//   schnorr_sig::verify_batch               <- src/batch.rs:31-50
+//   schnorr_sig::SignatureError             <- src/error.rs:13-31
+//
+// All compute happens on the GPU behind ssa_*; nothing here does field or curve arithmetic.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/schnorr_sig_amd.h"
+
+namespace schnorr_sig {
+
+constexpr size_t SCALAR_LENGTH = 32, BASEFIELD_LENGTH = 48, PUBLIC_KEY_LENGTH = 49, SIGNATURE_LENGTH = 81,
+                 KEYED_SIGNATURE_LENGTH = 130, AFFINE_PUBLIC_KEY_LENGTH = 96;  // src/constants.rs:12-30
+
+enum class SignatureError { InvalidPublicKey = 1, InvalidSignature = 2 };  // src/error.rs:13-18
+inline const char *to_string(SignatureError e) {                           // src/error.rs:20-31
+    return e == SignatureError::InvalidPublicKey ? "The public key is not an element of the prime subgroup."
+                                                 : "The signature is invalid or was incorrectly computed.";
+}
+// Result<(), SignatureError>: empty optional == Ok(())
+using Result = std::optional<SignatureError>;
+
+// Inputs the reference panics on (src/signature.rs:186, src/batch.rs:37-44,67,104)
+struct Panic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+using Rng = std::function<void(uint8_t *, size_t)>;  // fills a buffer with random bytes
+
+class Context {
+  public:
+    explicit Context(int device = 0, const void *params = nullptr, size_t params_len = 0) {
+        int rc = ssa_ctx_create(&ctx_, device, params, params_len);
+        if (rc != 0) throw std::runtime_error(std::string("ssa_ctx_create: ") + ssa_strerror(rc));
+    }
+    ~Context() { ssa_ctx_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    ssa_ctx *get() const { return ctx_; }
+
+  private:
+    ssa_ctx *ctx_ = nullptr;
+};
+
+inline Result status_to_result(int st) {
+    if (st == SSA_OK) return std::nullopt;
+    if (st == SSA_INVALID_PUBLIC_KEY) return SignatureError::InvalidPublicKey;
+    if (st == SSA_INVALID_SIGNATURE) return SignatureError::InvalidSignature;
+    if (st == SSA_MALFORMED) throw Panic("undecodable field element or scalar (the reference panics)");
+    throw std::runtime_error(std::string("schnorr_sig_amd: ") + ssa_strerror(st));
+}
+
+struct PrivateKey {  // src/private.rs:25
+    std::array<uint8_t, SCALAR_LENGTH> bytes{};
+};
+
+struct Signature;
+
+struct PublicKey {  // src/public.rs:24 -- the in-memory AffinePoint (x, y), canonical LE limbs
+    std::array<uint8_t, AFFINE_PUBLIC_KEY_LENGTH> affine{};
+    Result verify_signature(Context &cx, const Signature &sig, const uint8_t *msg, size_t len) const;
+};
+
+struct Signature {  // src/signature.rs:34-40, wire layout :208-214
+    std::array<uint8_t, SIGNATURE_LENGTH> bytes{};
+    // Signature::verify, src/signature.rs:181-205
+    Result verify(Context &cx, const uint8_t *msg, size_t len, const PublicKey &pk) const {
+        return status_to_result(
+            ssa_verify(cx.get(), bytes.data(), pk.affine.data(), msg, len, SSA_FLAG_CHECK_TORSION));
+    }
+    std::array<uint8_t, SIGNATURE_LENGTH> to_bytes() const { return bytes; }
+};
+
+inline Result PublicKey::verify_signature(Context &cx, const Signature &sig, const uint8_t *msg, size_t len) const {
+    return sig.verify(cx, msg, len, *this);
+}
+
+struct KeyPair {  // src/keypair.rs:48-53
+    PrivateKey private_key;
+    PublicKey public_key;
+
+    static void reduce_nonzero(Rng &rng, uint8_t out[32]) {
+        // 254 random bits: below q (255 bits, top byte 0x7a) and non-zero after forcing bit 0
+        rng(out, 32);
+        out[31] &= 0x3f;
+        out[0] |= 1;
+    }
+    // KeyPair::new, src/keypair.rs:57-65
+    static KeyPair create(Context &cx, Rng rng) {
+        KeyPair kp;
+        reduce_nonzero(rng, kp.private_key.bytes.data());
+        uint8_t sig[SIGNATURE_LENGTH], msg = 0;
+        int rc = ssa_keygen_sign_many(cx.get(), kp.private_key.bytes.data(), kp.private_key.bytes.data(), &msg,
+                                      nullptr, 1, 1, 1, kp.public_key.affine.data(), sig);
+        if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many: ") + ssa_strerror(rc));
+        return kp;
+    }
+    // KeyPair::sign, src/signature.rs:114-129
+    Signature sign(Context &cx, const uint8_t *msg, size_t len, Rng rng) const {
+        uint8_t nonce[32], pk[AFFINE_PUBLIC_KEY_LENGTH];
+        reduce_nonzero(rng, nonce);
+        Signature s;
+        uint8_t dummy = 0;
+        int rc = ssa_keygen_sign_many(cx.get(), private_key.bytes.data(), nonce, len ? msg : &dummy, nullptr, len,
+                                      len, 1, pk, s.bytes.data());
+        if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many: ") + ssa_strerror(rc));
+        return s;
+    }
+    Result verify_signature(Context &cx, const Signature &sig, const uint8_t *msg, size_t len) const {
+        return sig.verify(cx, msg, len, public_key);  // src/signature.rs:159-165
+    }
+};
+
+// verify_batch, src/batch.rs:31-50.  `rng` is accepted for signature compatibility and unused
+// (every signature is checked exactly; DESIGN.md lists the divergence classes).
+inline Result verify_batch(Context &cx, const std::vector<Signature> &signatures,
+                           const std::vector<PublicKey> &public_keys,
+                           const std::vector<std::pair<const uint8_t *, size_t>> &messages, Rng /*rng*/ = nullptr) {
+    if (signatures.size() != public_keys.size())
+        throw Panic("We should have the same number of signatures than public keys");  // src/batch.rs:37-40
+    if (messages.size() != public_keys.size())
+        throw Panic("We should have the same number of messages than public keys");    // src/batch.rs:41-44
+    const size_t n = signatures.size();
+    if (n == 0) return std::nullopt;
+    std::vector<uint8_t> sigs(n * SIGNATURE_LENGTH), pks(n * AFFINE_PUBLIC_KEY_LENGTH), flat;
+    std::vector<uint64_t> off(n + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        std::memcpy(&sigs[i * SIGNATURE_LENGTH], signatures[i].bytes.data(), SIGNATURE_LENGTH);
+        std::memcpy(&pks[i * AFFINE_PUBLIC_KEY_LENGTH], public_keys[i].affine.data(), AFFINE_PUBLIC_KEY_LENGTH);
+        flat.insert(flat.end(), messages[i].first, messages[i].first + messages[i].second);
+        off[i + 1] = flat.size();
+    }
+    flat.push_back(0);
+    return status_to_result(
+        ssa_verify_batch(cx.get(), sigs.data(), pks.data(), flat.data(), off.data(), 0, 0, n, 0));
+}
+
+}  // namespace schnorr_sig

@@ -1,0 +1,45 @@
+"""Batch-level sharding of a verification batch across the GPUs of one node.
+
+The path shards by signature (each verification reads only its own (sig, pk, msg):
+reference src/signature.rs:181-205), so there is no data-path collective.  The only
+exchange is the aggregate verdict: one sum all-reduce of the per-rank rejection counts
+(RCCL over xGMI on GPUs; gloo in the CPU tests), and an optional gather of status bytes.
+"""
+
+
+def shard_range(n, rank, world):
+    """Contiguous range [lo, hi) of rank `rank`: sizes differ by at most one, earlier ranks larger."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def aggregate_fail_count(local_count_tensor, dist=None):
+    """In-place sum over ranks of a 1-element integer tensor; returns it. dist=None: single rank."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(local_count_tensor, op=dist.ReduceOp.SUM)
+    return local_count_tensor
+
+
+def batch_verdict(total_fail):
+    """verify_batch's Result for the whole sharded batch (src/batch.rs:125-129): 0 Ok, 2 InvalidSignature."""
+    return 0 if int(total_fail) == 0 else 2
+
+
+def gather_status(local_status_tensor, n, rank, world, dist):
+    """All-gather of per-shard status bytes into the full n-vector (ragged shards padded to the max)."""
+    import torch
+    if dist is None or world == 1:
+        return local_status_tensor
+    width = (n + world - 1) // world
+    pad = torch.full((width,), 255, dtype=local_status_tensor.dtype, device=local_status_tensor.device)
+    pad[: local_status_tensor.numel()] = local_status_tensor
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        out.append(parts[r][: hi - lo])
+    return torch.cat(out)

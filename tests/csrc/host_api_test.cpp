@@ -1,0 +1,78 @@
+// Exercises the C++ host mirror (schnorr-sig_amd/host/schnorr_sig.hpp) in the shape of the
+// reference's own tests (src/signature.rs:334-426, src/batch.rs:139-179, tests/schnorr.rs:59-182).
+//   g++ -std=c++17 host_api_test.cpp -L../../schnorr-sig_amd/csrc -lschnorr_sig_amd -o host_api_test
+#include <cstdio>
+#include <random>
+
+#include "../../schnorr-sig_amd/host/schnorr_sig.hpp"
+
+using namespace schnorr_sig;
+
+#define CHECK(c)                                                    \
+    do {                                                            \
+        if (!(c)) {                                                 \
+            std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                               \
+        }                                                           \
+    } while (0)
+
+int main() {
+    Context cx(0);
+    std::mt19937_64 gen(42);
+    Rng rng = [&](uint8_t *p, size_t n) {
+        for (size_t i = 0; i < n; i++) p[i] = (uint8_t)gen();
+    };
+    uint8_t message[160];
+    rng(message, sizeof message);
+    KeyPair kp = KeyPair::create(cx, rng);
+    Signature sig = kp.sign(cx, message, sizeof message, rng);
+    CHECK(!sig.verify(cx, message, sizeof message, kp.public_key));               // is_ok()
+    CHECK(!kp.verify_signature(cx, sig, message, sizeof message));
+    CHECK(!kp.public_key.verify_signature(cx, sig, message, sizeof message));
+    uint8_t wrong[160];
+    std::memcpy(wrong, message, sizeof wrong);
+    wrong[0] = (uint8_t)(wrong[0] + 42);
+    Result r = sig.verify(cx, wrong, sizeof wrong, kp.public_key);
+    CHECK(r && *r == SignatureError::InvalidSignature);
+    // non-subgroup key of src/signature.rs:387-404
+    const uint64_t fx[12] = {0x9bfcd3244afcb637, 0x39005e478830b187, 0x7046f1c03b42c6cc, 0xb5eeac99193711e5,
+                             0x7fd272e724307b98, 0xcc371dd6dd5d8625, 0x9d03fdc216dfaae8, 0xbf4ade2a7665d9b8,
+                             0xf08b022d5b3262b7, 0x2eaf583a3cf15c6f, 0xa92531e4b1338285, 0x5b8157814141a7a7};
+    PublicKey small;
+    std::memcpy(small.affine.data(), fx, 96);
+    r = sig.verify(cx, message, sizeof message, small);
+    CHECK(r && *r == SignatureError::InvalidPublicKey);
+    CHECK(std::string(to_string(*r)) == "The public key is not an element of the prime subgroup.");
+    Signature e0 = sig;
+    std::memset(e0.bytes.data() + 49, 0, 32);
+    r = e0.verify(cx, message, sizeof message, kp.public_key);
+    CHECK(r && *r == SignatureError::InvalidSignature);
+
+    // verify_five_signatures, src/batch.rs:152-179
+    const char *texts[5] = {"Message1", "Message2", "Message3", "Message4", "Message5"};
+    std::vector<KeyPair> kps;
+    std::vector<Signature> sigs;
+    std::vector<PublicKey> pks;
+    std::vector<std::pair<const uint8_t *, size_t>> msgs;
+    for (int i = 0; i < 5; i++) {
+        KeyPair k = (i == 3 || i == 4) ? kps[0] : KeyPair::create(cx, rng);
+        kps.push_back(k);
+        sigs.push_back(k.sign(cx, (const uint8_t *)texts[i], 8, rng));
+        pks.push_back(k.public_key);
+        msgs.push_back({(const uint8_t *)texts[i], 8});
+    }
+    CHECK(!verify_batch(cx, sigs, pks, msgs, rng));
+    std::swap(pks[1], pks[2]);
+    r = verify_batch(cx, sigs, pks, msgs, rng);
+    CHECK(r && *r == SignatureError::InvalidSignature);
+    bool panicked = false;
+    try {
+        pks.pop_back();
+        verify_batch(cx, sigs, pks, msgs, rng);
+    } catch (const Panic &) {
+        panicked = true;
+    }
+    CHECK(panicked);
+    std::printf("host_api_test ok\n");
+    return 0;
+}

@@ -1,0 +1,94 @@
+"""CPU tests of the boundary: the C-ABI library loads without a GPU and exports every symbol
+include/schnorr_sig_amd.h declares; host-side mirror logic; loud failure without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import schnorr_sig_amd as ssa
+    hdr = open(os.path.join(ROOT, "include", "schnorr_sig_amd.h")).read()
+    declared = set(re.findall(r"\b(ssa_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(ssa.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export: " + name
+    assert declared == set(ssa.ABI_SYMBOLS)
+
+
+def test_header_constants_match_reference_lengths():
+    hdr = open(os.path.join(ROOT, "include", "schnorr_sig_amd.h")).read()
+    vals = dict(re.findall(r"#define (SSA_[A-Z_]+) +\(?(-?\d+)u?\)?", hdr))
+    assert int(vals["SSA_SIGNATURE_LENGTH"]) == 81 and int(vals["SSA_AFFINE_PK_LENGTH"]) == 96
+    assert int(vals["SSA_SCALAR_LENGTH"]) == 32 and int(vals["SSA_PARAMS_LENGTH"]) == 2816
+    assert (int(vals["SSA_OK"]), int(vals["SSA_INVALID_PUBLIC_KEY"]), int(vals["SSA_INVALID_SIGNATURE"]),
+            int(vals["SSA_MALFORMED"])) == (0, 1, 2, 3)
+
+
+def test_default_params_blob_is_the_committed_one():
+    import schnorr_sig_amd as ssa
+    blob = ssa.Engine.default_params()
+    assert blob == open(os.path.join(ROOT, "schnorr-sig_amd", "params", "params_default.bin"), "rb").read()
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    import torch
+    import schnorr_sig_amd as ssa
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        ssa.Engine(0)
+    with pytest.raises(RuntimeError):
+        ssa.Signature(bytes(81)).verify(b"m", ssa.PublicKey(bytes(96)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "schnorr-sig_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "schnorr_oracle" not in text and "pymodel" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+
+
+def test_error_vocabulary_and_messages():
+    import schnorr_sig_amd as ssa
+    assert str(ssa.SignatureError(ssa.SignatureError.InvalidPublicKey)) == \
+        "The public key is not an element of the prime subgroup."          # src/error.rs:24
+    assert str(ssa.SignatureError(ssa.SignatureError.InvalidSignature)) == \
+        "The signature is invalid or was incorrectly computed."            # src/error.rs:27
+    assert repr(ssa.SignatureError(ssa.SignatureError.InvalidPublicKey)) == "Err(InvalidPublicKey)"
+
+
+def test_verify_batch_length_mismatch_panics_like_the_reference():
+    import schnorr_sig_amd as ssa
+    with pytest.raises(ssa.MalformedInput, match="same number of signatures"):
+        ssa.verify_batch([ssa.Signature(bytes(81))], [], [b""])
+    with pytest.raises(ssa.MalformedInput, match="same number of messages"):
+        ssa.verify_batch([ssa.Signature(bytes(81))], [ssa.PublicKey(bytes(96))], [])
+    assert ssa.verify_batch([], [], []) is None      # empty batch is Ok (src/batch.rs)
+
+
+def test_pack_messages():
+    import schnorr_sig_amd as ssa
+    flat, off = ssa.pack_messages([b"ab", b"", b"cde"])
+    assert list(off) == [0, 2, 2, 5] and bytes(flat[:5]) == b"abcde"
+
+
+def test_shard_ranges_cover_batch():
+    from schnorr_sig_amd.sharding import shard_range, batch_verdict
+    for n in (0, 1, 7, 8, 1 << 20, (1 << 22) + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert batch_verdict(0) == 0 and batch_verdict(3) == 2

@@ -297,3 +297,122 @@ def test_empty_batch_and_batch_verdict(engine):
     st, nf = engine.verify_many(np.zeros((0, 81), np.uint8), np.zeros((0, 96), np.uint8),
                                 np.zeros((0, 8), np.uint8))
     assert st.size == 0 and nf == 0
+
+
+# ---------------------------------------------------------------- golden fixtures through the HIP path
+def _gold():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))
+
+
+def test_golden_vectors_through_hip(engine):
+    g = _gold()
+    a = np.array([r["a"] for r in g["fp6"]], dtype=np.uint64)
+    b = np.array([r["b"] for r in g["fp6"]], dtype=np.uint64)
+    assert (engine.debug_arith(0, a, b, 6) == np.array([r["mul"] for r in g["fp6"]], dtype=np.uint64)).all()
+    assert (engine.debug_arith(1, a, None, 6) == np.array([r["sqr"] for r in g["fp6"]], dtype=np.uint64)).all()
+    for rec in g["hash_field"]:
+        if rec["in"]:
+            got = engine.rescue_hash_many(np.array([rec["in"]], dtype=np.uint64))
+            assert [int(v) for v in got[0]] == rec["digest"]
+    for rec in g["signatures"]:
+        sk = np.frombuffer(bytes.fromhex(rec["sk"]), dtype=np.uint8)
+        nonce = np.frombuffer(bytes.fromhex(rec["nonce"]), dtype=np.uint8)
+        msg = bytes.fromhex(rec["msg"])
+        flat = np.frombuffer(msg + b"\0", dtype=np.uint8)
+        off = np.array([0, len(msg)], dtype=np.uint64)
+        pks, sigs = engine.keygen_sign_many(sk, nonce, flat, offsets=off)
+        assert pks[0].tobytes().hex() == rec["pk"] and sigs[0].tobytes().hex() == rec["sig"]
+        assert engine.hash_message_many(sigs, pks, flat, offsets=off)[0].tobytes().hex() == rec["digest"]
+        assert engine.verify_one(sigs[0].tobytes(), pks[0].tobytes(), msg, check_torsion=True) == 0
+        for neg in rec["negative"]:
+            st = engine.verify_one(bytes.fromhex(neg["sig"]), bytes.fromhex(neg["pk"]), bytes.fromhex(neg["msg"]), True)
+            assert st == neg["status"], neg["what"]
+            if "status_no_torsion" in neg:
+                assert engine.verify_one(bytes.fromhex(neg["sig"]), bytes.fromhex(neg["pk"]),
+                                         bytes.fromhex(neg["msg"]), False) == neg["status_no_torsion"]
+
+
+def test_reference_api_mirror_roundtrip(engine):
+    """KeyPair::new / sign / verify_signature / verify_batch through the object mirror, in the shape
+    of tests/schnorr.rs:59-146,149-182 and src/batch.rs:152-179 of the reference."""
+    import os as _os
+    import schnorr_sig_amd as ssa
+    rng = lambda k: _os.urandom(k)
+    kp = ssa.KeyPair.new(rng, engine)
+    sig = kp.sign(b"A random message", rng, engine)
+    assert sig.verify(b"A random message", kp.public_key, engine) is None
+    assert ssa.Signature.from_bytes(sig.to_bytes()) == sig
+    with pytest.raises(ssa.SignatureError) as ei:
+        sig.verify(b"A random messagf", kp.public_key, engine)
+    assert ei.value.kind == "InvalidSignature"
+    import pymodel as m
+    f = m.FIXTURE_SMALL_ORDER_PK
+    wrong = ssa.PublicKey(m.fp6_to_bytes48(f[0]) + m.fp6_to_bytes48(f[1]))
+    with pytest.raises(ssa.SignatureError) as ei:
+        sig.verify(b"A random message", wrong, engine)
+    assert ei.value.kind == "InvalidPublicKey" and repr(ei.value) == "Err(InvalidPublicKey)"
+    msgs = [b"Message1", b"Message2", b"Message3", b"Message4", b"Message5"]
+    kps = [ssa.KeyPair.new(rng, engine) for _ in range(3)]
+    kps += [kps[0], kps[0]]
+    sigs = [k.sign(mm, rng, engine) for k, mm in zip(kps, msgs)]
+    pks = [k.public_key for k in kps]
+    assert ssa.verify_batch(sigs, pks, msgs, rng, engine) is None
+    pks[1], pks[2] = pks[2], pks[1]
+    with pytest.raises(ssa.SignatureError):
+        ssa.verify_batch(sigs, pks, msgs, rng, engine)
+
+
+# ---------------------------------------------------------------- BASELINE sizes (configs 3 and 5)
+def test_full_size_2pow20_with_one_percent_corruption(engine, oracle):
+    """2^20 signatures, 1% corrupted (SURVEY.md §8(d) configs 3+5): the expected accept/reject vector is
+    known by construction; every corrupted lane and a random sample of honest lanes are also
+    recomputed by the CPU oracle.  Size-independent property: n_fail == #corrupted, status is
+    idempotent across runs and independent of the torsion flag except on the non-subgroup keys."""
+    import pymodel as m
+    rng = np.random.default_rng(0x5C4E0225)
+    n = 1 << 20
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, 80), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    nbad = n // 100
+    idx = rng.permutation(n)[:nbad]
+    f = m.FIXTURE_SMALL_ORDER_PK
+    fbytes = np.frombuffer(m.fp6_to_bytes48(f[0]) + m.fp6_to_bytes48(f[1]), dtype=np.uint8)
+    osigs, opks = sigs.copy(), pks.copy()
+    kinds = np.arange(nbad) % 5
+    sigs[idx[kinds == 0], 49] ^= 1
+    msgs[idx[kinds == 1], 40] ^= 0x10
+    pks[idx[kinds == 2]] = opks[(idx[kinds == 2] + 1) % n]
+    sigs[idx[kinds == 3], :49] = osigs[(idx[kinds == 3] + 1) % n, :49]
+    pks[idx[kinds == 4]] = fbytes
+    expect_t = np.zeros(n, dtype=np.uint8)
+    expect_t[idx] = 2
+    expect_t[idx[kinds == 4]] = 1
+    expect_b = np.where(expect_t != 0, 2, 0).astype(np.uint8)
+    st_t, nf_t = engine.verify_many(sigs, pks, msgs, check_torsion=True)
+    st_b, nf_b = engine.verify_many(sigs, pks, msgs, check_torsion=False)
+    assert (st_t == expect_t).all() and nf_t == nbad
+    assert (st_b == expect_b).all() and nf_b == nbad
+    st_again, _ = engine.verify_many(sigs, pks, msgs, check_torsion=True)
+    assert (st_again == st_t).all()
+    sample = np.concatenate([idx[:2000], rng.integers(0, n, size=2000)])
+    want = oracle.verify_many(sigs[sample], pks[sample], msgs[sample], check_torsion=True)
+    assert (st_t[sample] == want).all()
+    # keygen/sign kernel vs CPU signer on a 2^12 prefix (byte-exact)
+    pk_o, sig_o = oracle.keygen_sign_many(sks[:4096], nonces[:4096], rng.integers(0, 1, size=(4096, 0), dtype=np.uint8))
+    assert (pk_o == opks[:4096]).all()
+
+
+def test_cpp_host_mirror(tmp_path):
+    """The C++ mirror of the reference API (schnorr-sig_amd/host/schnorr_sig.hpp) over the C ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "schnorr-sig_amd", "csrc")
+    exe = str(tmp_path / "host_api_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests", "csrc", "host_api_test.cpp"),
+                           "-L" + libdir, "-lschnorr_sig_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "host_api_test ok" in out.stdout, out.stdout + out.stderr
