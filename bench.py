@@ -26,8 +26,9 @@ F6_MUL, F6_SQR = 36, 21
 W_DBL = 1 * F6_MUL + 8 * F6_SQR                 # dbl-2007-bl, a = 1
 W_MADD = 7 * F6_MUL + 4 * F6_SQR                # mixed addition
 W_ADD = 11 * F6_MUL + 5 * F6_SQR                # general Jacobian addition
-W_LADDER = 256 * W_DBL + 64 * W_ADD             # 64 signed 4-bit windows
-W_TABLE = W_DBL + 6 * W_ADD                     # 2P..8P
+W_LADDER = 256 * W_DBL + 64 * W_MADD            # 64 signed 4-bit windows, affine table
+W_INV = 4 * F6_MUL + 6 + 72 + 6                 # Fp6 inverse through the norm + one Fp inverse
+W_TABLE = 4 * W_DBL + 3 * W_MADD + 18 * F6_MUL + W_INV + 7 * (3 * F6_MUL + F6_SQR)  # 2P..8P, normalised
 W_BASE = 16 * W_MADD                            # comb, 16-bit windows
 W_FINAL = F6_MUL + F6_SQR + 2 * F6_SQR + F6_MUL  # x*Z^2 compare + on-curve check
 W_VERIFY_KERNEL = W_TABLE + W_LADDER + W_BASE + W_FINAL

@@ -463,3 +463,18 @@ FIXTURE_SMALL_ORDER_PK = (
     (0x9D03FDC216DFAAE8, 0xBF4ADE2A7665D9B8, 0xF08B022D5B3262B7,
      0x2EAF583A3CF15C6F, 0xA92531E4B1338285, 0x5B8157814141A7A7),
 )
+
+# Points of order 2 (y = 0), 5 and 10 on E(Fp6) (cofactor = 2*5*29*...), derived as [N/o]R from a
+# decompressed point R; used to exercise identity entries in the per-lane multiples tables.
+SMALL_ORDER_POINTS = {
+    5: ((16525022225432646804, 13399409047111918848, 12960134507503110866, 9400154066480193298,
+         12239491872660442389, 11775795367955543569),
+        (16955858041853764987, 2630571789795685815, 7754293585774190388, 2618474437792887236,
+         945460206037092674, 5566252518106206811)),
+    2: ((16464216994076148022, 10762729315666779701, 13396543320389503071, 6901070379872838024,
+         3684827223278792538, 13601246634833184273), (0, 0, 0, 0, 0, 0)),
+    10: ((13635412684447980835, 11213008678279131991, 5977087893765706792, 974128823796173302,
+          3486677043147322562, 9644894798482641728),
+         (8783693457566965682, 3196204548694481917, 8820385477742708675, 5433695813968208649,
+          9505825109225200576, 17799668965059873635)),
+}

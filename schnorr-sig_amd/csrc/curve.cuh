@@ -45,7 +45,8 @@ SSA_DEV jac jac_dbl(const jac &p) {
     return r;
 }
 
-// mixed addition p + (x2, y2); q_inf marks q as the identity.  7M + 4S on the generic path.
+// mixed addition p + (x2, y2): 7M + 4S on the generic path.  The affine pair (0, 0) -- not a
+// curve point since B != 0 -- is the table's encoding of the identity.
 SSA_DEV jac jac_madd(const jac &p, const aff &q) {
     fp6 Z1Z1 = f6_sqr(p.Z);
     fp6 U2 = f6_mul(q.x, Z1Z1);
@@ -53,9 +54,10 @@ SSA_DEV jac jac_madd(const jac &p, const aff &q) {
     fp6 H = f6_sub(U2, p.X);
     fp6 R = f6_sub(S2, p.Y);
     const bool p_inf = f6_is_zero(p.Z);
+    const bool q_inf = f6_is_zero(q.x) && f6_is_zero(q.y);
     const bool h0 = f6_is_zero(H);
     const bool r0 = f6_is_zero(R);
-    if (!p_inf && h0 && r0) return jac_dbl(p);  // p == q (rare, divergent)
+    if (!p_inf && !q_inf && h0 && r0) return jac_dbl(p);  // p == q (rare, divergent)
     fp6 HH = f6_sqr(H);
     fp6 HHH = f6_mul(H, HH);
     fp6 V = f6_mul(p.X, HH);
@@ -66,8 +68,9 @@ SSA_DEV jac jac_madd(const jac &p, const aff &q) {
     if (p_inf) {
         r.X = q.x;
         r.Y = q.y;
-        r.Z = f6_one();
+        r.Z = q_inf ? f6_zero() : f6_one();
     }
+    if (q_inf && !p_inf) r = p;
     return r;
 }
 

@@ -65,13 +65,17 @@ SSA_DEV u64 fp_neg(u64 a) { return fp_sub(0ull, a); }
 SSA_DEV bool fp_is_zero(u64 a) { return a == 0ull || a == FP_P; }
 SSA_DEV bool fp_eq(u64 a, u64 b) { return fp_canon(a) == fp_canon(b); }
 
+// (2^32 - 1) * h as a 64-bit value.  hipcc emits one v_mad_u64_u32 by 0xffffffff for this; a
+// hand-written v_sub_co/v_subbrev pair measured 8 % slower in the Fp-mul probe (VCC dependency).
+SSA_DEV u64 eps_times(u32 h) { return ((u64)h << 32) - h; }
+
 // Reduce lo + 2^64*(h0 + 2^32*h1), h1 < 2^64 allowed as a full 64-bit "top" value:
 // value = lo + EPS*h0 - (top),  top = h1 + 2^32*h2 given as a u64.
 SSA_DEV u64 fp_reduce_parts(u64 lo, u32 h0, u64 top) {
     u64 t = lo - top;
     u32 bw = lo < top;
     t -= bw ? (u64)FP_EPS : 0ull;            // no second borrow: t >= 2^64 - top > EPS here
-    u64 m = ((u64)h0 << 32) - h0;            // EPS * h0
+    u64 m = eps_times(h0);                   // EPS * h0
     u64 r = t + m;
     u32 c = r < t;
     r += c ? (u64)FP_EPS : 0ull;             // cannot carry again (m <= 2^64 - 2^33 + 1)

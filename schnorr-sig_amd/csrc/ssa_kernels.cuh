@@ -9,8 +9,9 @@
 // HBM layout: inputs stay in the caller's AoS byte records (81-B signatures, 96-B keys,
 // message bytes); per-lane intermediates live in the context workspace:
 //   ws_h    n x 4 u64       challenge scalars
-//   ws_tab  n x 8 x 18 u64  per-lane Jacobian multiples 1P..8P, lane-contiguous so that a lane's
-//                           gather of one entry is nine 16-byte loads from one 144-byte row
+//   ws_tab  n x 8 x 24 u64  per-lane affine multiples 1P..8P (96 B used per 192-B row; the rest is
+//                           scratch of the batch normalisation), lane-contiguous so that a lane's
+//                           gather of one entry is six 16-byte loads from one row
 //   gtab    16 x 65536 x 12 u64 affine multiples d*2^(16w)*G (100 MB, Infinity-Cache resident)
 #pragma once
 #include "curve.cuh"
@@ -22,7 +23,7 @@ constexpr int GW_BITS = 16;
 constexpr int GW_COUNT = 16;
 constexpr size_t GTAB_ENTRIES = (size_t)GW_COUNT << GW_BITS;
 constexpr int PTAB_ENTRIES = 8;
-constexpr int PTAB_ENTRY_U64 = 18;
+constexpr int PTAB_ENTRY_U64 = 24;  // X, Y, Z, prefix product while building; affine x, y after
 
 constexpr u32 ST_OK = 0, ST_INVALID_PK = 1, ST_INVALID_SIG = 2, ST_MALFORMED = 3;
 
@@ -196,25 +197,96 @@ SSA_DEV aff ld_aff(const u64 *__restrict__ row) {
     return p;
 }
 
-// multiples 1P..8P of a lane's point into its table row block
-SSA_DEV void build_ptab(u64 *__restrict__ tab, const jac &p) {
-    st_jac(tab, p);
-    jac p2 = jac_dbl(p);
-    st_jac(tab + PTAB_ENTRY_U64, p2);
-    jac acc = p2;
+SSA_DEV void st_f6(u64 *__restrict__ p, const fp6 &a) {
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(p);
+#pragma unroll
+    for (int i = 0; i < 3; i++) q[i] = make_ulonglong2(a.c[2 * i], a.c[2 * i + 1]);
+}
+SSA_DEV fp6 ld_f6(const u64 *__restrict__ p) {
+    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p);
+    fp6 a;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ulonglong2 v = q[i];
+        a.c[2 * i] = v.x;
+        a.c[2 * i + 1] = v.y;
+    }
+    return a;
+}
+SSA_DEV void st_aff(u64 *__restrict__ row, const aff &p) {
+    st_f6(row, p.x);
+    st_f6(row + 6, p.y);
+}
+
+// row-to-row point operations used only while building the table (cold code, kept out of line)
+SSA_FN void tab_dbl(u64 *__restrict__ dst, const u64 *__restrict__ src) { st_jac(dst, jac_dbl(ld_jac(src))); }
+SSA_FN void tab_madd(u64 *__restrict__ dst, const u64 *__restrict__ src, const u64 *__restrict__ paff) {
+    st_jac(dst, jac_madd(ld_jac(src), ld_aff(paff)));
+}
+
+// Affine multiples 1P..8P of a lane's point into its table rows: 4 doublings + 3 mixed additions
+// in Jacobian form, then one shared inversion (Montgomery's trick) to make every entry affine.
+// Multiples that are the identity (P of order <= 8: E(Fp6) has cofactor 2*5*29*...) are stored as
+// the (0, 0) sentinel jac_madd understands.
+SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
+    constexpr int R = PTAB_ENTRY_U64;
+    if (p_inf) {
+        aff z;
+        z.x = f6_zero();
+        z.y = f6_zero();
 #pragma unroll 1
-    for (int e = 2; e < PTAB_ENTRIES; e++) {  // 3P .. 8P by repeated addition of P
-        acc = jac_add(acc, p);
-        st_jac(tab + e * PTAB_ENTRY_U64, acc);
+        for (int e = 0; e < PTAB_ENTRIES; e++) st_aff(tab + e * R, z);
+        return;
+    }
+    st_jac(tab, jac_from_aff(p));                 // row 0 doubles as affine P: (x, y, Z = 1)
+    tab_dbl(tab + 1 * R, tab);                    // 2P
+    tab_madd(tab + 2 * R, tab + 1 * R, tab);      // 3P = 2P + P
+    tab_dbl(tab + 3 * R, tab + 1 * R);            // 4P
+    tab_madd(tab + 4 * R, tab + 3 * R, tab);      // 5P = 4P + P
+    tab_dbl(tab + 5 * R, tab + 2 * R);            // 6P
+    tab_madd(tab + 6 * R, tab + 5 * R, tab);      // 7P = 6P + P
+    tab_dbl(tab + 7 * R, tab + 3 * R);            // 8P
+    // forward pass: prefix products of the (non-zero) Z's, kept in the rows' fourth slot
+    fp6 c = f6_one();
+#pragma unroll 1
+    for (int e = 1; e < PTAB_ENTRIES; e++) {
+        fp6 z = ld_f6(tab + e * R + 12);
+        if (f6_is_zero(z)) z = f6_one();
+        c = f6_mul(c, z);
+        st_f6(tab + e * R + 18, c);
+    }
+    fp6 inv = f6_inv(c);
+    // backward pass: 1/Z_e = inv * prefix_{e-1};  inv *= Z_e
+#pragma unroll 1
+    for (int e = PTAB_ENTRIES - 1; e >= 1; e--) {
+        fp6 z = ld_f6(tab + e * R + 12);
+        const bool zero = f6_is_zero(z);
+        if (zero) z = f6_one();
+        fp6 zinv = inv;
+        if (e > 1) zinv = f6_mul(inv, ld_f6(tab + (e - 1) * R + 18));
+        inv = f6_mul(inv, z);
+        const fp6 zi2 = f6_sqr(zinv);
+        aff a;
+        a.x = f6_mul(ld_f6(tab + e * R), zi2);
+        a.y = f6_mul(ld_f6(tab + e * R + 6), f6_mul(zi2, zinv));
+        if (zero) {
+            a.x = f6_zero();
+            a.y = f6_zero();
+        }
+        st_aff(tab + e * R, a);
     }
 }
 
-// [k]P from the lane's table with signed 4-bit windows (offset recoding): 64 x (4 dbl + add)
-SSA_FN jac mul_ptab(const u64 *__restrict__ tab, sc256 k) {
+// [k]P from the lane's affine table with signed 4-bit windows (offset recoding):
+// 64 x (4 doublings + 1 mixed addition), every lane in lock-step.
+SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k) {
     u32 top;
     const sc256 kr = sc_recode_offset(k, top);
     jac acc = jac_identity();
-    if (top) acc = ld_jac(tab);
+    if (top) {
+        const aff p1 = ld_aff(tab);
+        if (!(f6_is_zero(p1.x) && f6_is_zero(p1.y))) acc = jac_from_aff(p1);
+    }
 #pragma unroll 1
     for (int w = 63; w >= 0; w--) {
 #pragma unroll 1
@@ -222,9 +294,9 @@ SSA_FN jac mul_ptab(const u64 *__restrict__ tab, sc256 k) {
         const int digit = (int)sc_nibble(kr, (u32)w) - 8;
         if (digit != 0) {
             const int mag = digit < 0 ? -digit : digit;
-            jac q = ld_jac(tab + (mag - 1) * PTAB_ENTRY_U64);
-            q = jac_neg_if(q, digit < 0);
-            acc = jac_add(acc, q);
+            aff q = ld_aff(tab + (mag - 1) * PTAB_ENTRY_U64);
+            q.y = f6_select(digit < 0, q.y, f6_neg(q.y));
+            acc = jac_madd(acc, q);
         }
     }
     return acc;
@@ -265,21 +337,27 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
             status = ST_MALFORMED;
         } else {
             u64 *tab = ws_tab + i * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64);
-            jac pj = jac_from_aff(P);
-            if (inf) pj = jac_identity();
-            build_ptab(tab, pj);
-            if (flags & 1u) {                               // is_torsion_free, :182-184
-                sc256 q;
+            build_ptab(tab, P, inf);
+            // pass 0 (only with SSA_FLAG_CHECK_TORSION): [q]P == O, is_torsion_free, :182-184
+            // pass 1: [h]P.  One rolled loop so that the ladder body exists once in the code.
+            sc256 h;
 #pragma unroll
-                for (int k = 0; k < 4; k++) q.w[k] = SC_Q(k);
-                const jac t = mul_ptab(tab, q);
-                if (!jac_is_identity(t)) status = ST_INVALID_PK;
+            for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
+            jac r = jac_identity();
+#pragma unroll 1
+            for (int pass = (flags & 1u) ? 0 : 1; pass < 2; pass++) {
+                sc256 k = h;
+                if (pass == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) k.w[j] = SC_Q(j);
+                }
+                r = mul_ptab(tab, k);
+                if (pass == 0 && !jac_is_identity(r)) {
+                    status = ST_INVALID_PK;
+                    break;
+                }
             }
             if (status == ST_OK) {
-                sc256 h;
-#pragma unroll
-                for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
-                jac r = mul_ptab(tab, h);                   // [h]P
                 r = add_base_mul(r, gtab, e);               // + [e]G, :196-198
                 // r.get_x() == x_felt (:200): X == x * Z^2; the identity's x is taken as 0
                 bool eq;
@@ -510,7 +588,7 @@ __global__ void ssa_k_debug_mul(const u64 *__restrict__ a, const u64 *__restrict
         p.y.c[j] = pb[6 + j];
     }
     u64 *tab = ws_tab + i * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64);
-    build_ptab(tab, pb[12] ? jac_identity() : jac_from_aff(p));
+    build_ptab(tab, p, pb[12] != 0);
     const jac r = mul_ptab(tab, k);
     const aff o = jac_to_aff(r);
 #pragma unroll

@@ -27,14 +27,14 @@ static void st(uint64_t *p, const fp6 &a) {
 void ha_f6_mul(const uint64_t *a, const uint64_t *b, uint64_t *o) { st(o, f6_mul(ld(a), ld(b))); }
 void ha_f6_sqr(const uint64_t *a, uint64_t *o) { st(o, f6_sqr(ld(a))); }
 void ha_f6_inv(const uint64_t *a, uint64_t *o) { st(o, f6_inv(ld(a))); }
-// [k]P through build_ptab + mul_ptab; tab must hold 8*18 u64
+// [k]P through build_ptab + mul_ptab; tab must hold 8*24 u64
 int ha_mul_ptab(const uint64_t *k4, const uint64_t *p12, int inf, uint64_t *tab, uint64_t *o12) {
     sc256 k;
     for (int i = 0; i < 4; i++) k.w[i] = k4[i];
     aff p;
     p.x = ld(p12);
     p.y = ld(p12 + 6);
-    build_ptab(tab, inf ? jac_identity() : jac_from_aff(p));
+    build_ptab(tab, p, inf != 0);
     jac r = mul_ptab(tab, k);
     aff a = jac_to_aff(r);
     st(o12, a.x);

@@ -107,6 +107,11 @@ def test_scalar_mul_table_path(engine, oracle):
     ks += [int.from_bytes(rng.bytes(32), "little") for _ in range(46)]
     pts = [g] * len(ks) + [f] * 8 + [None] * 2
     ks = ks + [Q, 5, 2 * Q // 5, Q // 5, 2, 3, 1, 0] + [5, 0]
+    # points of order 2, 5, 10: multiples inside the 1P..8P table are the identity
+    for o in (2, 5, 10):
+        sm = list(range(0, 21)) + [Q, Q - 1, 2**255 - 19, int("8" * 64, 16)]
+        pts += [m.SMALL_ORDER_POINTS[o]] * len(sm)
+        ks += sm
     a = np.zeros((len(ks), 4), dtype=np.uint64)
     for i, k in enumerate(ks):
         a[i] = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint64)
@@ -251,6 +256,51 @@ def test_adversarial_e_hits_table_point(engine, oracle):
     st, _ = engine.verify_many(sigs, pks, msgs, check_torsion=True)
     want = oracle.verify_many(sigs, pks, msgs, check_torsion=True)
     assert (st == want).all()
+
+
+def test_small_order_public_keys(engine, oracle):
+    """pk of order 2 / 5 / 10 (on the curve, outside the prime subgroup): InvalidPublicKey with the
+    torsion check; without it (batch semantics) the ladder must still be exact although multiples
+    in the per-lane table are the identity."""
+    import pymodel as m
+    rng = np.random.default_rng(21)
+    sigs, pks, msgs = [], [], []
+    for o in (2, 5, 10):
+        p = m.SMALL_ORDER_POINTS[o]
+        pk96 = m.fp6_to_bytes48(p[0]) + m.fp6_to_bytes48(p[1])
+        for t in range(12):
+            rx = m.pt_mul(1000 + t, m.default_params().generator())[0]
+            e = int.from_bytes(rng.bytes(32), "little") % Q
+            if t == 0:
+                e = 0
+            sigs.append(m.fp6_to_bytes48(rx) + b"\0" + e.to_bytes(32, "little"))
+            pks.append(pk96)
+            msgs.append(bytes(rng.integers(0, 256, size=24, dtype=np.uint8)))
+    sigs = np.frombuffer(b"".join(sigs), dtype=np.uint8).reshape(-1, 81)
+    pks = np.frombuffer(b"".join(pks), dtype=np.uint8).reshape(-1, 96)
+    msgs = np.frombuffer(b"".join(msgs), dtype=np.uint8).reshape(-1, 24)
+    for torsion in (True, False):
+        st, _ = engine.verify_many(sigs, pks, msgs, check_torsion=torsion)
+        want = oracle.verify_many(sigs, pks, msgs, check_torsion=torsion)
+        assert (st == want).all()
+        assert (st == (1 if torsion else 2)).all()
+    # and a forged acceptance: with pk of order 2, [h]P is O or P; pick e so that R matches
+    g = m.default_params().generator()
+    p2 = m.SMALL_ORDER_POINTS[2]
+    pk96 = m.fp6_to_bytes48(p2[0]) + m.fp6_to_bytes48(p2[1])
+    forged = []
+    for e in range(1, 9):
+        for addp in (False, True):
+            r = m.pt_mul(e, g)
+            if addp:
+                r = m.pt_add(r, p2)
+            forged.append(m.fp6_to_bytes48(r[0]) + b"\0" + e.to_bytes(32, "little"))
+    fs = np.frombuffer(b"".join(forged), dtype=np.uint8).reshape(-1, 81)
+    fp = np.tile(np.frombuffer(pk96, dtype=np.uint8), (len(forged), 1))
+    fm = np.zeros((len(forged), 5), dtype=np.uint8)
+    st, _ = engine.verify_many(fs, fp, fm, check_torsion=False)
+    want = oracle.verify_many(fs, fp, fm, check_torsion=False)
+    assert (st == want).all() and (st == 0).sum() >= len(forged) // 4   # roughly half are accepted
 
 
 def test_identity_public_key(engine, oracle):

@@ -112,9 +112,12 @@ def test_scalar_mul_table_path(ha, oracle):
     f = m.FIXTURE_SMALL_ORDER_PK
     ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, Q - 1, Q, Q + 1, 2**255 - 1, 2**256 - 1, int("8" * 64, 16),
           int("7" * 64, 16), int("f" * 63, 16)] + [rnd.randrange(2**256) for _ in range(12)]
-    tab = np.zeros(8 * 18, np.uint64)
-    for p in (g, f, None):
-        for k in ks:
+    tab = np.zeros(8 * 24, np.uint64)
+    small = [m.SMALL_ORDER_POINTS[o] for o in (2, 5, 10)]
+    for o, p in m.SMALL_ORDER_POINTS.items():
+        assert m.on_curve(p) and m.pt_mul(o, p) is None
+    for p in (g, f, None) + tuple(small):
+        for k in (ks if p not in small else list(range(0, 23)) + ks[9:22]):
             pv, pi = _pt(p)
             o = np.zeros(12, np.uint64)
             inf = ha.ha_mul_ptab(p_(arr([(k >> (64 * i)) & (2**64 - 1) for i in range(4)])), p_(pv), pi, p_(tab), p_(o))
