@@ -28,13 +28,14 @@ def _ptr(a, typ):
 
 
 class Oracle:
-    def __init__(self, blob_path=PARAMS_BLOB, native=False):
+    def __init__(self, blob_path=PARAMS_BLOB, native=False, blob=None):
         path = os.path.join(_HERE, "libschnorr_oracle_native.so" if native else "libschnorr_oracle.so")
         src = os.path.join(_HERE, "schnorr_oracle.c")
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             path = build(native)
         self.lib = C.CDLL(path)
-        blob = open(blob_path, "rb").read()
+        if blob is None:
+            blob = open(blob_path, "rb").read()
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         self.lib.so_init.argtypes = [C.c_void_p, C.c_size_t]
         rc = self.lib.so_init(buf, len(blob))

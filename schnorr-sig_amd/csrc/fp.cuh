@@ -151,6 +151,25 @@ SSA_DEV void acc_mac(fp_acc &s, u64 a, u64 b) {
 #endif
 }
 
+// s += a*m for a 32-bit multiplier (small MDS entries): two mads instead of four
+SSA_DEV void acc_mac32(fp_acc &s, u64 a, u32 m) {
+    u32 a0 = lo32(a), a1 = hi32(a);
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 t0;
+    asm("v_mad_u64_u32 %0, %4, %5, %7, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %6, %7, %1\n\t"
+        "v_addc_co_u32 %2, %4, 0, %2, %4\n\t"
+        "v_addc_co_u32 %3, vcc, 0, %3, vcc"
+        : "+v"(s.c0), "+v"(s.c1), "+v"(s.k0), "+v"(s.k1), "=&s"(t0)
+        : "v"(a0), "v"(a1), "v"(m)
+        : "vcc");
+#else
+    u64 p, t;
+    p = (u64)a0 * m; t = s.c0 + p; s.k0 += t < p; s.c0 = t;
+    p = (u64)a1 * m; t = s.c1 + p; s.k1 += t < p; s.c1 = t;
+#endif
+}
+
 // first product into a fresh accumulator: no carries possible on c0/c2, one on c1
 SSA_DEV void acc_init(fp_acc &s, u64 a, u64 b) {
     u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);

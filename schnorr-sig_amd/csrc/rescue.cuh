@@ -58,7 +58,10 @@ SSA_DEV u64 inv_sbox(u64 x) {
 constexpr int RS_STRIDE = 256;  // == blockDim.x of every kernel that hashes
 constexpr int RS_LDS_U64 = 2 * 12 * RS_STRIDE;
 
-// dst <- MDS * src + ark (lazy 12-term accumulation per output, one reduction each)
+// dst <- MDS * src + ark (lazy 12-term accumulation per output, one reduction each).
+// SMALL: every MDS entry is below 2^32 (flag set by the host when it loads the blob), which
+// halves the multiplier work of the layer.
+template <bool SMALL>
 SSA_DEV void mds_ark(const u64 *src, u64 *dst, const u64 *__restrict__ mds, const u64 *__restrict__ ark) {
     u64 v[12];
 #pragma unroll
@@ -67,16 +70,25 @@ SSA_DEV void mds_ark(const u64 *src, u64 *dst, const u64 *__restrict__ mds, cons
     for (int i = 0; i < 12; i++) {
         const u64 *row = mds + i * 12;
         fp_acc acc;
-        acc_init(acc, v[0], row[0]);
+        if (SMALL) {
+            acc_zero(acc);
 #pragma unroll
-        for (int j = 1; j < 12; j++) acc_mac(acc, v[j], row[j]);
+            for (int j = 0; j < 12; j++) acc_mac32(acc, v[j], (u32)row[j]);
+        } else {
+            acc_init(acc, v[0], row[0]);
+#pragma unroll
+            for (int j = 1; j < 12; j++) acc_mac(acc, v[j], row[j]);
+        }
         dst[i * RS_STRIDE] = fp_add(acc_reduce(acc), ark[i]);
     }
 }
 
 // permutation of the state in plane A (plane B is scratch); result back in plane A
+constexpr u32 PRM_FLAG_SMALL_MDS = 1u;
+
 SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ prm) {
     const u32 nr = prm->n_rounds;
+    const bool small = (prm->flags & PRM_FLAG_SMALL_MDS) != 0;
 #pragma unroll 1
     for (u32 r = 0; r < nr; r++) {
 #pragma unroll 1
@@ -85,14 +97,16 @@ SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ pr
             A[i * RS_STRIDE] = x;
             A[(i + 6) * RS_STRIDE] = y;
         }
-        mds_ark(A, B, prm->mds, prm->ark1 + 12 * r);
+        if (small) mds_ark<true>(A, B, prm->mds, prm->ark1 + 12 * r);
+        else mds_ark<false>(A, B, prm->mds, prm->ark1 + 12 * r);
 #pragma unroll 1
         for (int i = 0; i < 6; i++) {
             const u64 x = inv_sbox(B[i * RS_STRIDE]), y = inv_sbox(B[(i + 6) * RS_STRIDE]);
             B[i * RS_STRIDE] = x;
             B[(i + 6) * RS_STRIDE] = y;
         }
-        mds_ark(B, A, prm->mds, prm->ark2 + 12 * r);
+        if (small) mds_ark<true>(B, A, prm->mds, prm->ark2 + 12 * r);
+        else mds_ark<false>(B, A, prm->mds, prm->ark2 + 12 * r);
     }
 }
 

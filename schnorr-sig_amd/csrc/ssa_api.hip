@@ -130,6 +130,10 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         std::memcpy(&hp, k_default_params, sizeof hp);
     }
     if (int rc = validate_params(hp)) return rc;
+    hp.flags = 0;  // derived flags are the library's, not the caller's
+    bool small_mds = true;
+    for (int i = 0; i < 144; i++) small_mds = small_mds && hp.mds[i] <= 0xffffffffull;
+    if (small_mds) hp.flags |= PRM_FLAG_SMALL_MDS;
     HIP_TRY(hipSetDevice(device));
     ssa_ctx *ctx = new ssa_ctx();
     ctx->device = device;

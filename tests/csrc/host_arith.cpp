@@ -4,6 +4,7 @@
 // machine without a GPU.  The shipped library never executes this code on the CPU.
 //   hipcc --cuda-host-only -x hip -O2 -shared -fPIC host_arith.cpp -o libhost_arith.so
 #define SSA_HOST_TEST 1
+#include <cstring>
 #include "../../schnorr-sig_amd/csrc/ssa_kernels.cuh"
 
 using namespace ssa;
@@ -56,10 +57,14 @@ int ha_point_add(const uint64_t *a12, int a_inf, const uint64_t *b12, int b_inf,
     return jac_is_identity(r);
 }
 // hash_field with the LDS planes emulated by a host array
-void ha_hash_field(const void *params, const uint64_t *felts, uint32_t n, uint64_t *digest) {
+// flags != 0 forces the small-MDS path (the library derives the flag itself at ctx_create)
+void ha_hash_field(const void *params, int flags, const uint64_t *felts, uint32_t n, uint64_t *digest) {
     static uint64_t planes[RS_LDS_U64];
     uint64_t d[4];
-    sponge_hash(planes, planes + 12 * RS_STRIDE, (const DevParams *)params, n,
+    DevParams prm;
+    memcpy(&prm, params, sizeof prm);
+    prm.flags = (u32)flags;
+    sponge_hash(planes, planes + 12 * RS_STRIDE, &prm, n,
                 [&](u32 idx) -> u64 { return felts[idx]; }, d);
     for (int i = 0; i < 4; i++) digest[i] = d[i];
 }

@@ -466,3 +466,61 @@ def test_cpp_host_mirror(tmp_path):
                            "-L" + libdir, "-lschnorr_sig_amd", "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "host_api_test ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_alternative_parameter_blobs(oracle):
+    """The Rescue instance and sponge layout are data: a blob with 8 rounds, full-width MDS
+    entries (generic multiplier path), capacity-first layout and Rescue-Prime padding must give
+    the oracle's digests and signatures with no kernel change (how upstream's real constants
+    would be dropped in)."""
+    import struct
+    import schnorr_sig_amd as ssa
+    from oracle import Oracle
+    base = bytearray(ssa.Engine.default_params())
+    rng = np.random.default_rng(99)
+    variants = []
+    b = bytearray(base)                                  # (1) generic MDS entries, 8 rounds
+    struct.pack_into("<IIiIII", b, 8, 8, 0, 11, 0, 0, 0)
+    mds = rand_felts(rng, 144)
+    struct.pack_into("<144Q", b, 32, *[int(v) for v in mds])
+    struct.pack_into("<12Q", b, 1184 + 96 * 7, *[int(v) for v in rand_felts(rng, 12)])
+    struct.pack_into("<12Q", b, 1952 + 96 * 7, *[int(v) for v in rand_felts(rng, 12)])
+    variants.append(bytes(b))
+    b = bytearray(base)                                  # (2) capacity-first, padded sponge, digest = state[4..8]
+    struct.pack_into("<IIiIII", b, 8, 7, 4, -1, 1, 4, 0)
+    variants.append(bytes(b))
+    b = bytearray(base)                                  # (3) length in state[0], rate = state[4..12]
+    struct.pack_into("<IIiIII", b, 8, 7, 4, 0, 0, 4, 0)
+    variants.append(bytes(b))
+    for blob in variants:
+        orc = Oracle(blob=blob)
+        eng = ssa.Engine(0, params=blob)
+        try:
+            for width in (0, 5, 8, 13, 25):
+                felts = rand_felts(rng, (64, width)) if width else np.zeros((64, 0), dtype=np.uint64)
+                want = orc.hash_field_many(felts) if width else np.stack([orc.hash_field(np.zeros(0, np.uint64))] * 64)
+                assert (eng.rescue_hash_many(felts) == want).all()
+            n = 64
+            sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+            msgs = rng.integers(0, 256, size=(n, 33), dtype=np.uint8)
+            pks, sigs = eng.keygen_sign_many(sks, nonces, msgs)
+            pks_o, sigs_o = orc.keygen_sign_many(sks, nonces, msgs)
+            assert (pks == pks_o).all() and (sigs == sigs_o).all()
+            sigs[5, 50] ^= 2
+            st, nf = eng.verify_many(sigs, pks, msgs, check_torsion=True)
+            assert nf == 1 and st[5] == 2 and (orc.verify_many(sigs, pks, msgs, check_torsion=True) == st).all()
+        finally:
+            eng.close()
+    Oracle()   # restore the default blob in the shared library's global state
+
+
+def test_invalid_parameter_blob_is_rejected():
+    import schnorr_sig_amd as ssa
+    bad = bytearray(ssa.Engine.default_params())
+    bad[0] = ord("X")
+    with pytest.raises(RuntimeError, match="invalid parameter blob"):
+        ssa.Engine(0, params=bytes(bad))
+    bad = bytearray(ssa.Engine.default_params())
+    bad[32:40] = b"\xff" * 8          # MDS entry >= p
+    with pytest.raises(RuntimeError, match="invalid parameter blob"):
+        ssa.Engine(0, params=bytes(bad))

@@ -131,9 +131,10 @@ def test_hash_field_and_hash_message(ha, oracle):
     rnd = random.Random(4)
     for n in (0, 1, 7, 8, 9, 16, 17, 25, 40):
         felts = arr([rnd.randrange(P) for _ in range(n)]) if n else np.zeros(1, np.uint64)
-        d = np.zeros(4, np.uint64)
-        ha.ha_hash_field(blob.ctypes.data_as(C.c_void_p), p_(felts), n, p_(d))
-        assert (d == oracle.hash_field(felts[:n])).all(), n
+        for flags in (0, 1):     # generic and small-entry MDS paths
+            d = np.zeros(4, np.uint64)
+            ha.ha_hash_field(blob.ctypes.data_as(C.c_void_p), flags, p_(felts), n, p_(d))
+            assert (d == oracle.hash_field(felts[:n])).all(), (n, flags)
     sig = np.frombuffer(bytes(rnd.randrange(256) for _ in range(81)), np.uint8).copy()
     pk = np.frombuffer(bytes(rnd.randrange(256) for _ in range(96)), np.uint8).copy()
     for i in range(0, 48, 8):
