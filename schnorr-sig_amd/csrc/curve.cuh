@@ -174,21 +174,22 @@ SSA_DEV sc256 sc_reduce256(sc256 a) {
     return a;
 }
 
-// Offset recoding for signed 4-bit windows: k' = k + 0x88..8 (mod 2^256) and carry-out;
-// digit_w = nibble_w(k') - 8 in [-8, 7],  k = carry*16^64 + sum digit_w 16^w.
-SSA_DEV sc256 sc_recode_offset(const sc256 &k, u32 &carry_out) {
+// Offset recoding for signed 4-bit windows of a scalar k < 2^255 (true for h, e and q):
+// k' = k + 0x0888...8 (63 nibbles of 8).  digit_w = nibble_w(k') - 8 in [-8, 7] for w < 63 and the
+// top digit nibble_63(k') in [0, 8] is unsigned:  k = sum digit_w 16^w, no carry-out.
+SSA_DEV sc256 sc_recode_offset(const sc256 &k) {
     sc256 r;
     u64 carry = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        u64 s = k.w[i] + 0x8888888888888888ULL;
+        const u64 off = (i == 3) ? 0x0888888888888888ULL : 0x8888888888888888ULL;
+        u64 s = k.w[i] + off;
         u64 c1 = s < k.w[i];
         u64 s2 = s + carry;
         u64 c2 = s2 < s;
         r.w[i] = s2;
         carry = c1 | c2;
     }
-    carry_out = (u32)carry;
     return r;
 }
 // nibble w (0..63) of a 256-bit value with a dynamic index, registers only

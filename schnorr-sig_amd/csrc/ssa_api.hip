@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -62,6 +63,7 @@ struct ssa_ctx {
     // staging for the host-buffer entry points
     DevBuf st_sigs, st_pks, st_inf, st_msgs, st_off, st_status, st_aux, st_aux2;
     bool timing = false;
+    unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;
 };
 
@@ -137,6 +139,10 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     HIP_TRY(hipSetDevice(device));
     ssa_ctx *ctx = new ssa_ctx();
     ctx->device = device;
+    if (const char *vb = std::getenv("SSA_VERIFY_BLOCK")) {
+        const int v = std::atoi(vb);
+        if (v == 64 || v == 128 || v == 256) ctx->verify_block = (unsigned)v;
+    }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return SSA_ERR_HIP;
@@ -283,7 +289,7 @@ extern "C" int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const
     });
     if (rc) return rc;
     return timed_launch(ctx, "ssa_k_verify", [&] {
-        hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_sigs, d_pks,
+        hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(n, ctx->verify_block)), dim3(ctx->verify_block), 0, ctx->stream, d_sigs, d_pks,
                            d_pk_inf, (const u64 *)ctx->ws_h.p, (const u64 *)ctx->d_gtab,
                            (u64 *)ctx->ws_tab.p, n, flags, d_status_out, d_fail);
     });

@@ -277,18 +277,19 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
     }
 }
 
-// [k]P from the lane's affine table with signed 4-bit windows (offset recoding):
-// 64 x (4 doublings + 1 mixed addition), every lane in lock-step.
+// [k]P, k < 2^255, from the lane's affine table with signed 4-bit windows (offset recoding):
+// the top window only selects its table entry, then 63 x (4 doublings + 1 mixed addition) with
+// every lane in lock-step.
 SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k) {
-    u32 top;
-    const sc256 kr = sc_recode_offset(k, top);
+    const sc256 kr = sc_recode_offset(k);
     jac acc = jac_identity();
-    if (top) {
-        const aff p1 = ld_aff(tab);
-        if (!(f6_is_zero(p1.x) && f6_is_zero(p1.y))) acc = jac_from_aff(p1);
+    const u32 top = sc_nibble(kr, 63u);   // in [0, 8]
+    if (top != 0) {
+        const aff p = ld_aff(tab + (top - 1) * PTAB_ENTRY_U64);
+        if (!(f6_is_zero(p.x) && f6_is_zero(p.y))) acc = jac_from_aff(p);
     }
 #pragma unroll 1
-    for (int w = 63; w >= 0; w--) {
+    for (int w = 62; w >= 0; w--) {
 #pragma unroll 1
         for (int d = 0; d < 4; d++) acc = jac_dbl(acc);
         const int digit = (int)sc_nibble(kr, (u32)w) - 8;

@@ -102,14 +102,14 @@ def test_scalar_mul_table_path(engine, oracle):
     rng = np.random.default_rng(3)
     g = m.default_params().generator()
     f = m.FIXTURE_SMALL_ORDER_PK
-    ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, Q - 1, Q, Q + 1, 2**255 - 1, 2**256 - 1, 0x8888888888888888,
-          int("8" * 64, 16), int("7" * 64, 16), int("f" * 63, 16)]
-    ks += [int.from_bytes(rng.bytes(32), "little") for _ in range(46)]
+    ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, Q - 1, Q, Q + 1, 2**255 - 1, 0x8888888888888888,
+          int("7" + "8" * 63, 16), int("7" * 64, 16), int("f" * 63, 16)]
+    ks += [int.from_bytes(rng.bytes(32), "little") >> 1 for _ in range(46)]
     pts = [g] * len(ks) + [f] * 8 + [None] * 2
     ks = ks + [Q, 5, 2 * Q // 5, Q // 5, 2, 3, 1, 0] + [5, 0]
     # points of order 2, 5, 10: multiples inside the 1P..8P table are the identity
     for o in (2, 5, 10):
-        sm = list(range(0, 21)) + [Q, Q - 1, 2**255 - 19, int("8" * 64, 16)]
+        sm = list(range(0, 21)) + [Q, Q - 1, 2**255 - 19, int("7" + "8" * 63, 16)]
         pts += [m.SMALL_ORDER_POINTS[o]] * len(sm)
         ks += sm
     a = np.zeros((len(ks), 4), dtype=np.uint64)

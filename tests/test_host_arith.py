@@ -110,8 +110,8 @@ def test_scalar_mul_table_path(ha, oracle):
     rnd = random.Random(3)
     g = m.default_params().generator()
     f = m.FIXTURE_SMALL_ORDER_PK
-    ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, Q - 1, Q, Q + 1, 2**255 - 1, 2**256 - 1, int("8" * 64, 16),
-          int("7" * 64, 16), int("f" * 63, 16)] + [rnd.randrange(2**256) for _ in range(12)]
+    ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, Q - 1, Q, Q + 1, 2**255 - 1, int("7" + "8" * 63, 16),
+          int("7" * 64, 16), int("f" * 63, 16)] + [rnd.randrange(2**255) for _ in range(12)]
     tab = np.zeros(8 * 24, np.uint64)
     small = [m.SMALL_ORDER_POINTS[o] for o in (2, 5, 10)]
     for o, p in m.SMALL_ORDER_POINTS.items():
