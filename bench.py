@@ -146,6 +146,13 @@ def main():
         value = world * n * args.steps / elapsed
         w_kernel = W_VERIFY_KERNEL
         achieved = w_kernel * n / (k_verify_ms * 1e-3) if k_verify_ms > 0 else 0.0
+        traffic = None   # HBM bytes per ssa_k_verify launch from the committed PMC passes (same workload)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_v2.json")) as fh:
+                if n == 1 << 20:
+                    traffic = json.load(fh)["ssa_k_verify"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "schnorr_verifications_per_sec",
             "value": value,
@@ -176,7 +183,8 @@ def main():
                 "unit": "GFp-mul/s",
                 "frac": achieved / PEAK_FPMUL,
                 "work_per_unit": w_kernel,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01)",
             },
             "roofline_hbm": {
                 "bound": "hbm",
