@@ -13,6 +13,8 @@
  *                              BASELINE.json's north_star asks for)
  *   ssa_hash_message_many   <- hash_message                 src/signature.rs:274-306
  *   ssa_rescue_hash_many    <- RescueHash::hash_field       src/signature.rs:303
+ *   ssa_decompress_many     <- PublicKey::from_bytes / AffinePoint::from_compressed
+ *                                                           src/public.rs:54-56, src/batch.rs:104
  *   ssa_keygen_sign_many    <- KeyPair::new / KeyPair::sign src/keypair.rs:57-65,
  *                                                           src/signature.rs:114-129
  *   status codes            <- SignatureError               src/error.rs:13-18
@@ -46,6 +48,7 @@ extern "C" {
 #define SSA_SIGNATURE_LENGTH 81   /* src/constants.rs:27 */
 #define SSA_AFFINE_PK_LENGTH 96   /* 2 x BASEFIELD_LENGTH, src/constants.rs:18 */
 #define SSA_SCALAR_LENGTH 32      /* src/constants.rs:12 */
+#define SSA_PUBLIC_KEY_LENGTH 49  /* compressed wire form, src/constants.rs:21 */
 #define SSA_DIGEST_LENGTH 32      /* hash_message output, src/signature.rs:274 */
 #define SSA_PARAMS_LENGTH 2816
 
@@ -124,6 +127,13 @@ int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces
                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
                          size_t msg_len, size_t n, uint8_t *pks_out, uint8_t *sigs_out);
 
+/* PublicKey::from_bytes (src/public.rs:54-56): n x 49-byte compressed points (48 bytes of x, flag
+ * byte: bit 7 = infinity, bit 6 = sort flag, other bits clear) -> n x 96-byte affine points.
+ * status_out[i] = 0 ok, 1 "decompression failed" (CtOption is_none); pk_inf_out[i] (optional) = 1
+ * for the identity encoding [0;48] || 0x80 (src/public.rs:95-101). */
+int ssa_decompress_many(ssa_ctx *ctx, const uint8_t *compressed, size_t n, uint8_t *pks_out,
+                        uint8_t *pk_inf_out, uint8_t *status_out);
+
 /* ---- device-buffer entry points: same semantics, every pointer is a device pointer ----
  * (work is enqueued on the context's stream; outputs are valid after ssa_ctx_sync) */
 int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
@@ -140,6 +150,8 @@ int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_
                                 const uint8_t *d_msgs, const uint64_t *d_msg_off,
                                 size_t msg_stride, size_t msg_len, size_t n, uint8_t *d_pks_out,
                                 uint8_t *d_sigs_out);
+int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t n, uint8_t *d_pks_out,
+                               uint8_t *d_pk_inf_out, uint8_t *d_status_out);
 int ssa_ctx_sync(ssa_ctx *ctx);
 
 /* ---- arithmetic probes (unit parity with the oracle; not part of the reference API) --- */

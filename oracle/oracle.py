@@ -210,5 +210,19 @@ class Oracle:
                                                 _ptr(off, _u64p), C.c_size_t(stride), C.c_size_t(mlen),
                                                 C.c_size_t(n), _ptr(coeffs, _u8p), int(threads)))
 
+    def decompress(self, c49):
+        """-> (pk96 bytes, is_identity) or None when decompression fails."""
+        c = np.frombuffer(bytes(c49), np.uint8).copy()
+        pk = np.zeros(96, np.uint8)
+        inf = C.c_int(0)
+        ok = self.lib.so_decompress(_ptr(c, _u8p), _ptr(pk, _u8p), C.byref(inf))
+        return (pk.tobytes(), bool(inf.value)) if ok else None
+
+    def compress(self, pk96, pk_inf=False):
+        pk = np.frombuffer(bytes(pk96), np.uint8).copy()
+        c = np.zeros(49, np.uint8)
+        self.lib.so_compress(_ptr(pk, _u8p), int(pk_inf), _ptr(c, _u8p))
+        return c.tobytes()
+
     def hw_threads(self):
         return int(self.lib.so_hw_threads())

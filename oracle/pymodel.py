@@ -217,17 +217,53 @@ def is_torsion_free(pt):
     return pt_mul(Q, pt) is None
 
 
+def lex_largest(y):
+    """Sort flag of a compressed point (bit 6 of byte 48): scanning c5 down to c0, the first
+    non-zero coefficient is above (p-1)/2.  Convention recalled from the zkcrypto lineage the
+    cheetah crate follows (Fp2::lexicographically_largest generalised); UNPINNED -- the reference
+    only pins bit 7 (infinity, src/public.rs:95-101) and that 0xff is invalid (:150-156)."""
+    for c in reversed(y):
+        if c:
+            return c > (P - 1) // 2
+    return False
+
+
 def pt_decompress_x(x, want_sign=None):
     """Point from an x coordinate (AffinePoint::from_compressed, src/batch.rs:104).
-    Returns (x, y) with the lexicographically smaller root unless want_sign is given;
-    None when x is not on the curve.  Only x matters to the reference's x-only compare."""
+    Returns (x, y) with the root whose lex_largest() equals want_sign (False by default);
+    None when x is not on the curve."""
     rhs = f6_add(f6_add(f6_mul(f6_sqr(x), x), x), CURVE_B)
     y = f6_sqrt(rhs)
     if y is None:
         return None
-    yn = f6_neg(y)
-    lo, hi = (y, yn) if y <= yn else (yn, y)
-    return (x, hi if want_sign else lo)
+    if lex_largest(y) != bool(want_sign):
+        y = f6_neg(y)
+    return (x, y)
+
+
+def pt_compress(pt):
+    """AffinePoint::to_compressed: 48 bytes of x || flag byte (bit 7 infinity, bit 6 sort flag)."""
+    if pt is None:
+        return bytes(48) + bytes([0x80])
+    return fp6_to_bytes48(pt[0]) + bytes([0x40 if lex_largest(pt[1]) else 0])
+
+
+def pt_decompress(b49):
+    """AffinePoint::from_compressed (src/public.rs:54-56, src/batch.rs:104).
+    Returns ('ok', point-or-None) or ('invalid', None)."""
+    flag = b49[48]
+    if flag & 0x3F:
+        return "invalid", None
+    inf, sort = bool(flag & 0x80), bool(flag & 0x40)
+    x = fp6_from_bytes48(b49[:48])
+    if x is None:
+        return "invalid", None
+    if inf:
+        return ("ok", None) if (x == F6_ZERO and not sort) else ("invalid", None)
+    pt = pt_decompress_x(x, want_sign=sort)
+    if pt is None:
+        return "invalid", None
+    return "ok", pt
 
 
 # ----------------------------------------------------------------------------
@@ -271,6 +307,8 @@ def derive_generator():
     while True:
         pt = pt_decompress_x(f6(k, 0, 0, 0, 0, 0))
         if pt is not None:
+            if f6_neg(pt[1]) < pt[1]:      # the blob's G was fixed with the tuple-smaller root
+                pt = (pt[0], f6_neg(pt[1]))
             g = pt_mul(COFACTOR, pt)
             if g is not None:
                 return g, k
@@ -405,10 +443,8 @@ def sign(sk, r, message, prm=None):
     rp = pt_mul(r, g)
     h = scalar_from_digest(hash_message(rp[0], pk, message, prm))
     e = (r - sk * h) % Q
-    # CompressedPoint: 48 bytes of x || flag byte (bit 7 = infinity; bit 6 = y-sign, unpinned)
-    yn = f6_neg(rp[1])
-    flag = 0x40 if rp[1] > yn else 0
-    return fp6_to_bytes48(rp[0]) + bytes([flag]) + e.to_bytes(32, "little"), pk
+    # CompressedPoint: 48 bytes of x || flag byte (bit 7 = infinity; bit 6 = sort flag, unpinned)
+    return pt_compress(rp) + e.to_bytes(32, "little"), pk
 
 
 def verify(sig81, pk, message, check_torsion=True, prm=None):

@@ -557,6 +557,13 @@ int so_is_torsion_free(const u64 px[6], const u64 py[6], int p_inf) {
 int so_on_curve(const u64 px[6], const u64 py[6]) { return pt_on_curve(ld6(px), ld6(py)); }
 
 /* ------------------------------------------------------------------ schnorr-sig */
+/* sort flag of a compressed point: from c5 down, the first non-zero coefficient exceeds (p-1)/2
+ * (zkcrypto-style lexicographically_largest; unpinned) */
+static int fp6_lex_largest(fp6 y) {
+    for (int i = 5; i >= 0; i--)
+        if (y.c[i]) return y.c[i] > (FP_P - 1) / 2;
+    return 0;
+}
 static int fp6_from_bytes48(const uint8_t *b, fp6 *out) {
     for (int i = 0; i < 6; i++) {
         out->c[i] = rd64(b + 8 * i);
@@ -593,15 +600,8 @@ int so_sign(const uint8_t sk32[32], const uint8_t nonce32[32], const uint8_t pk9
     sc256 skh = sc_mulmod(&sk, &h);
     sc256 e = sc_submod(r, &skh);                                   /* :124 */
     memcpy(sig81, rx48, 48);
-    /* CompressedPoint flag byte: bit 7 infinity (src/public.rs:95-101), bit 6 y-sign (unpinned) */
-    fp6 ryn = fp6_neg(ry);
-    int sign = 0;
-    for (int i = 0; i < 6; i++) {
-        if (ry.c[i] != ryn.c[i]) {
-            sign = ry.c[i] > ryn.c[i];
-            break;
-        }
-    }
+    /* CompressedPoint flag byte: bit 7 infinity (src/public.rs:95-101), bit 6 sort flag (unpinned) */
+    int sign = fp6_lex_largest(ry);
     sig81[48] = finite ? (sign ? 0x40 : 0) : 0x80;
     sc_to_bytes(&e, sig81 + 49);
     return 0;
@@ -717,14 +717,7 @@ int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *
                 bad = 1;
                 continue;
             }
-            fp6 ryn = fp6_neg(ry);
-            int sign = 0;
-            for (int k = 0; k < 6; k++)
-                if (ry.c[k] != ryn.c[k]) {
-                    sign = ry.c[k] > ryn.c[k];
-                    break;
-                }
-            if (sign != ((sig[48] >> 6) & 1)) ry = ryn;
+            if (fp6_lex_largest(ry) != ((sig[48] >> 6) & 1)) ry = fp6_neg(ry);
             jpt rp = j_from_affine(x_felt.c, ry.c, 0);
             jpt np = j_from_affine(px.c, py.c, 0);
             np = j_neg(&np);                                        /* :106 */
@@ -747,4 +740,38 @@ int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *
     j_to_affine(&left, &lx, &ly);
     j_to_affine(&right, &rx, &ry);
     return fp6_eq(lx, rx) ? SO_OK : SO_INVALID_SIGNATURE;           /* :125-129 */
+}
+
+/* AffinePoint::from_compressed (src/public.rs:54-56, src/batch.rs:104): returns 1 and the affine
+ * point (pk_inf = 1 for the identity encoding [0;48] || 0x80), 0 when decompression fails. */
+int so_decompress(const uint8_t c49[49], uint8_t pk96[96], int *pk_inf) {
+    memset(pk96, 0, 96);
+    *pk_inf = 0;
+    uint8_t flag = c49[48];
+    if (flag & 0x3f) return 0;
+    int inf = flag >> 7, sort = (flag >> 6) & 1;
+    fp6 x;
+    if (!fp6_from_bytes48(c49, &x)) return 0;
+    if (inf) {
+        if (!fp6_is_zero(x) || sort) return 0;
+        *pk_inf = 1;
+        return 1;
+    }
+    fp6 rhs = fp6_add(fp6_add(fp6_mul(fp6_sqr(x), x), x), CURVE_B), y;
+    if (!fp6_sqrt(rhs, &y)) return 0;
+    if (fp6_lex_largest(y) != sort) y = fp6_neg(y);
+    fp6_to_bytes48(&x, pk96);
+    fp6_to_bytes48(&y, pk96 + 48);
+    return 1;
+}
+void so_compress(const uint8_t pk96[96], int pk_inf, uint8_t c49[49]) {
+    memset(c49, 0, 49);
+    if (pk_inf) {
+        c49[48] = 0x80;
+        return;
+    }
+    fp6 y;
+    memcpy(c49, pk96, 48);
+    fp6_from_bytes48(pk96 + 48, &y);
+    c49[48] = fp6_lex_largest(y) ? 0x40 : 0;
 }

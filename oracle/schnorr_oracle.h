@@ -69,6 +69,8 @@ int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *
                         const uint64_t *off, size_t stride, size_t msg_len, size_t n,
                         const uint8_t *coeffs, int threads);
 int so_hw_threads(void);
+int so_decompress(const uint8_t c49[49], uint8_t pk96[96], int *pk_inf);
+void so_compress(const uint8_t pk96[96], int pk_inf, uint8_t c49[49]);
 
 #ifdef __cplusplus
 }

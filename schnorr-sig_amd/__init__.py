@@ -85,6 +85,8 @@ def _load():
         "ssa_hash_message_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
         "ssa_rescue_hash_many_device": (i32, [vp, vp, u32, sz, vp]),
         "ssa_keygen_sign_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, vp]),
+        "ssa_decompress_many": (i32, [vp, vp, sz, vp, vp, vp]),
+        "ssa_decompress_many_device": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_debug_arith": (i32, [vp, i32, vp, vp, sz, sz, sz, vp, sz]),
         "ssa_bench_fpmul": (i32, [vp, i32, C.POINTER(C.c_double)]),
     }
@@ -218,6 +220,17 @@ class Engine:
                                          _ptr(pks), _ptr(sigs)), "ssa_keygen_sign_many")
         return pks, sigs
 
+    def decompress_many(self, compressed):
+        """n x 49-byte compressed points -> (pks uint8[n,96], is_identity uint8[n], status uint8[n])."""
+        c = _np_u8(compressed, 49)
+        n = c.shape[0]
+        pks = np.zeros((n, 96), dtype=np.uint8)
+        inf = np.zeros(n, dtype=np.uint8)
+        st = np.full(n, 255, dtype=np.uint8)
+        _check(_lib.ssa_decompress_many(self._ctx, _ptr(c), n, _ptr(pks), _ptr(inf), _ptr(st)),
+               "ssa_decompress_many")
+        return pks, inf, st
+
     # ---- device-buffer entry points (raw device addresses, e.g. torch.Tensor.data_ptr()) ----
     def set_stream(self, hip_stream):
         _check(_lib.ssa_ctx_set_stream(self._ctx, C.c_void_p(hip_stream or 0)), "ssa_ctx_set_stream")
@@ -297,6 +310,33 @@ class PublicKey:
 
     def verify_signature(self, signature, message):  # src/signature.rs:170-176
         return signature.verify(message, self)
+
+    @classmethod
+    def from_bytes(cls, b49, engine=None):
+        """PublicKey::from_bytes (src/public.rs:54-56): None when decompression fails.  The identity
+        encoding decodes to a key whose affine bytes are zero and `is_identity` is set."""
+        b = bytes(b49)
+        if len(b) != PUBLIC_KEY_LENGTH:
+            raise ValueError("compressed public key needs 49 bytes")
+        pks, inf, st = (engine or default_engine()).decompress_many(np.frombuffer(b, np.uint8))
+        if st[0] != 0:
+            return None
+        pk = cls(pks[0].tobytes())
+        pk.is_identity = bool(inf[0])
+        return pk
+
+    def to_bytes(self):
+        """PublicKey::to_bytes (src/public.rs:49-51): x || flag byte (formatting only, no arithmetic)."""
+        if getattr(self, "is_identity", False):
+            return bytes(48) + bytes([0x80])
+        p = 2**64 - 2**32 + 1
+        flag = 0
+        for i in range(5, -1, -1):
+            c = int.from_bytes(self.affine[48 + 8 * i: 56 + 8 * i], "little")
+            if c:
+                flag = 0x40 if c > (p - 1) // 2 else 0
+                break
+        return self.affine[:48] + bytes([flag])
 
     def __eq__(self, o):
         return isinstance(o, PublicKey) and o.affine == self.affine

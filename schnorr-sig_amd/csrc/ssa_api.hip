@@ -310,6 +310,17 @@ extern "C" int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, c
     });
 }
 
+extern "C" int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t n,
+                                          uint8_t *d_pks_out, uint8_t *d_pk_inf_out, uint8_t *d_status_out) {
+    if (!ctx || (n && (!d_compressed || !d_pks_out || !d_status_out))) return SSA_ERR_ARG;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return timed_launch(ctx, "ssa_k_decompress", [&] {
+        hipLaunchKernelGGL(ssa_k_decompress, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_compressed, n,
+                           d_pks_out, d_pk_inf_out, d_status_out);
+    });
+}
+
 // ------------------------------------------------------------------ host entry points
 static size_t msgs_bytes(const uint64_t *off, size_t stride, size_t len, size_t n) {
     if (n == 0) return 0;
@@ -480,6 +491,25 @@ extern "C" int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint
         return rc;
     HIP_TRY(hipMemcpyAsync(pks_out, ctx->st_aux.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(sigs_out, ctx->st_aux2.p, n * 81, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int ssa_decompress_many(ssa_ctx *ctx, const uint8_t *compressed, size_t n, uint8_t *pks_out,
+                                   uint8_t *pk_inf_out, uint8_t *status_out) {
+    if (!ctx || (n && (!compressed || !pks_out || !status_out))) return SSA_ERR_ARG;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const void *p;
+    if (int rc = stage_up(ctx, ctx->st_sigs, compressed, n * 49, &p)) return rc;
+    if (ctx->st_aux.reserve(n * 96) || ctx->st_aux2.reserve(n + 16) || ctx->st_status.reserve(n + 16))
+        return SSA_ERR_HIP;
+    if (int rc = ssa_decompress_many_device(ctx, (const u8 *)p, n, (u8 *)ctx->st_aux.p, (u8 *)ctx->st_aux2.p,
+                                            (u8 *)ctx->st_status.p))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(pks_out, ctx->st_aux.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
+    if (pk_inf_out) HIP_TRY(hipMemcpyAsync(pk_inf_out, ctx->st_aux2.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(status_out, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -5,6 +5,7 @@
 //   ssa_k_gtable   fixed-base comb table for G (BASEPOINT_TABLE, src/signature.rs:20,116)
 //   ssa_k_sign     keygen + sign (src/public.rs:26-32, src/signature.rs:114-129)
 //   ssa_k_rescue   RescueHash::hash_field on raw felt rows (src/signature.rs:303)
+//   ssa_k_decompress  AffinePoint::from_compressed (src/public.rs:54-56, src/batch.rs:104)
 //
 // HBM layout: inputs stay in the caller's AoS byte records (81-B signatures, 96-B keys,
 // message bytes); per-lane intermediates live in the context workspace:
@@ -15,6 +16,7 @@
 //   gtab    16 x 65536 x 12 u64 affine multiples d*2^(16w)*G (100 MB, Infinity-Cache resident)
 #pragma once
 #include "curve.cuh"
+#include "fp3.cuh"
 #include "rescue.cuh"
 
 namespace ssa {
@@ -497,20 +499,57 @@ ssa_k_sign(const DevParams *__restrict__ prm, const u64 *__restrict__ gtab,
     const sc256 e = sc_add_mod(r, sc_neg_mod(sc_mul_mod(sk, h)));        // :124
     u8 *sig = sigs_out + 81 * i;
     st_fp6(sig, rp.x);
-    // CompressedPoint flag byte: bit 7 = infinity (src/public.rs:95-101); bit 6 = y is the
-    // lexicographically larger root (unpinned; ignored by verify)
-    const fp6 yn = f6_canon(f6_neg(rp.y));
-    bool larger = false, decided = false;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        if (!decided && rp.y.c[k] != yn.c[k]) {
-            larger = rp.y.c[k] > yn.c[k];
-            decided = true;
-        }
-    }
-    sig[48] = jac_is_identity(rj) ? 0x80 : (larger ? 0x40 : 0x00);
+    // CompressedPoint flag byte: bit 7 = infinity (src/public.rs:95-101); bit 6 = sort flag
+    // (lexicographically largest y; unpinned; ignored by Signature::verify)
+    sig[48] = jac_is_identity(rj) ? 0x80 : (f6_lex_largest(rp.y) ? 0x40 : 0x00);
 #pragma unroll
     for (int k = 0; k < 4; k++) st_u64_le(sig + 49 + 8 * k, e.w[k]);
+}
+#endif  // SSA_HOST_TEST
+
+// ------------------------------------------------------------------------------------------
+// AffinePoint::from_compressed: 48 bytes of x || flag byte (bit 7 infinity, bit 6 sort flag, other
+// bits must be clear) -> affine (x, y).  status 0 = ok, 1 = "decompression failed".
+SSA_DEV u32 decompress_lane(const u8 *__restrict__ c, aff &out, bool &is_inf) {
+    const u32 flag = c[48];
+    is_inf = false;
+    out.x = f6_zero();
+    out.y = f6_zero();
+    if (flag & 0x3fu) return 1;
+    const bool inf = (flag & 0x80u) != 0, sort = (flag & 0x40u) != 0;
+    bool ok = true;
+    const fp6 x = ld_fp6(c, ok);
+    if (!ok) return 1;
+    if (inf) {
+        if (!f6_is_zero(x) || sort) return 1;
+        is_inf = true;
+        return 0;
+    }
+    fp6 rhs = f6_add(f6_mul(f6_sqr(x), x), x);   // x^3 + x + (u + 395)
+    rhs.c[0] = fp_add(rhs.c[0], 395ull);
+    rhs.c[1] = fp_add(rhs.c[1], 1ull);
+    fp6 y;
+    if (!f6_sqrt(rhs, y)) return 1;
+    y = f6_canon(y);
+    if (f6_lex_largest(y) != sort) y = f6_canon(f6_neg(y));
+    out.x = x;
+    out.y = y;
+    return 0;
+}
+
+#ifndef SSA_HOST_TEST
+__global__ void __launch_bounds__(256)
+ssa_k_decompress(const u8 *__restrict__ comp, size_t n, u8 *__restrict__ pks_out, u8 *__restrict__ inf_out,
+                 u8 *__restrict__ status_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    aff p;
+    bool inf;
+    const u32 st = decompress_lane(comp + 49 * i, p, inf);
+    st_fp6(pks_out + 96 * i, p.x);
+    st_fp6(pks_out + 96 * i + 48, p.y);
+    if (inf_out) inf_out[i] = inf ? 1 : 0;
+    status_out[i] = (u8)st;
 }
 #endif  // SSA_HOST_TEST
 

@@ -28,6 +28,21 @@ static void st(uint64_t *p, const fp6 &a) {
 void ha_f6_mul(const uint64_t *a, const uint64_t *b, uint64_t *o) { st(o, f6_mul(ld(a), ld(b))); }
 void ha_f6_sqr(const uint64_t *a, uint64_t *o) { st(o, f6_sqr(ld(a))); }
 void ha_f6_inv(const uint64_t *a, uint64_t *o) { st(o, f6_inv(ld(a))); }
+int ha_f6_sqrt(const uint64_t *a, uint64_t *o) {
+    fp6 r = f6_zero();
+    bool ok = f6_sqrt(ld(a), r);
+    st(o, r);
+    return ok;
+}
+int ha_decompress(const uint8_t *c49, uint64_t *o12, int *inf) {
+    aff p;
+    bool is_inf;
+    u32 s = decompress_lane(c49, p, is_inf);
+    st(o12, p.x);
+    st(o12 + 6, p.y);
+    *inf = is_inf;
+    return (int)s;
+}
 // [k]P through build_ptab + mul_ptab; tab must hold 8*24 u64
 int ha_mul_ptab(const uint64_t *k4, const uint64_t *p12, int inf, uint64_t *tab, uint64_t *o12) {
     sc256 k;

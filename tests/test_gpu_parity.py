@@ -524,3 +524,57 @@ def test_invalid_parameter_blob_is_rejected():
     bad[32:40] = b"\xff" * 8          # MDS entry >= p
     with pytest.raises(RuntimeError, match="invalid parameter blob"):
         ssa.Engine(0, params=bytes(bad))
+
+
+# ---------------------------------------------------------------- decompression
+def test_decompress_many_vs_oracle(engine, oracle):
+    """PublicKey::from_bytes / AffinePoint::from_compressed: random keys round-trip, both sort flags,
+    x values off the curve, and the reference's encoding fixtures (src/public.rs:95-156)."""
+    import pymodel as m
+    import schnorr_sig_amd as ssa
+    rng = np.random.default_rng(31)
+    n = 2048
+    sks = make_scalars(rng, n)
+    pks, _ = engine.keygen_sign_many(sks, sks, np.zeros((n, 1), np.uint8))
+    comp = np.zeros((n, 49), dtype=np.uint8)
+    for i in range(n):
+        comp[i] = np.frombuffer(ssa.PublicKey(pks[i].tobytes()).to_bytes(), dtype=np.uint8)
+    out, inf, st = engine.decompress_many(comp)
+    assert (st == 0).all() and (inf == 0).all() and (out == pks).all()
+    for i in range(0, n, 97):
+        assert oracle.compress(pks[i].tobytes()) == comp[i].tobytes()
+    flipped = comp.copy()
+    flipped[:, 48] ^= 0x40                      # the other root: same x, y negated
+    out2, _, st2 = engine.decompress_many(flipped)
+    assert (st2 == 0).all() and (out2[:, :48] == pks[:, :48]).all() and (out2[:, 48:] != pks[:, 48:]).any()
+    for i in range(0, n, 211):
+        assert oracle.decompress(flipped[i].tobytes())[0] == out2[i].tobytes()
+    # random x: about half are not on the curve
+    rx = rand_felts(rng, (1024, 6))
+    rc = np.zeros((1024, 49), dtype=np.uint8)
+    rc[:, :48] = rx.view(np.uint8).reshape(1024, 48)
+    rc[:, 48] = rng.integers(0, 2, size=1024, dtype=np.uint8) * 0x40
+    out3, inf3, st3 = engine.decompress_many(rc)
+    n_ok = 0
+    for i in range(1024):
+        want = oracle.decompress(rc[i].tobytes())
+        assert (st3[i] == 0) == (want is not None)
+        if want is not None:
+            n_ok += 1
+            assert out3[i].tobytes() == want[0]
+    assert 350 < n_ok < 700
+    # encoding fixtures of the reference
+    fixtures = [bytes(48) + b"\x80",                      # identity (src/public.rs:95-101)          ok, inf
+                bytes(49),                                # 49 zero bytes (:115-120)                   None
+                b"\xff" * 49,                             # (:122-129)                                 None
+                comp[0, :48].tobytes() + b"\xff",         # flag byte 255 (:150-156)                   None
+                bytes(48) + b"\xc0",                      # infinity with the sort flag                None
+                bytes([1]) + bytes(47) + b"\x80"]         # infinity with x != 0                       None
+    fx = np.frombuffer(b"".join(fixtures), dtype=np.uint8).reshape(-1, 49)
+    _, inf4, st4 = engine.decompress_many(fx)
+    assert list(st4) == [0, 1, 1, 1, 1, 1] and inf4[0] == 1
+    pk = ssa.PublicKey.from_bytes(fixtures[0], engine)
+    assert pk is not None and pk.is_identity and pk.to_bytes() == fixtures[0]
+    assert ssa.PublicKey.from_bytes(fixtures[1], engine) is None
+    rt = ssa.PublicKey.from_bytes(comp[5].tobytes(), engine)
+    assert rt == ssa.PublicKey(pks[5].tobytes()) and rt.to_bytes() == comp[5].tobytes()

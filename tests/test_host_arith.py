@@ -161,3 +161,41 @@ def test_scalar_arith(ha):
         o = np.zeros(4, np.uint64)
         ha.ha_sc_reduce(p_(arr([(v >> (64 * i)) & (2**64 - 1) for i in range(4)])), p_(o))
         assert int.from_bytes(o.tobytes(), "little") == v % Q
+
+
+def test_fp6_sqrt_and_decompress(ha, oracle):
+    """Tower-descent square root (two Fp3 Tonelli-Shanks runs) vs the oracle's generic Fp6
+    Tonelli-Shanks, and from_compressed incl. the reference's encoding fixtures."""
+    import pymodel as m
+    rnd = random.Random(6)
+    cases = [[rnd.randrange(P) for _ in range(6)] for _ in range(60)]
+    cases += [[5, 0, 0, 0, 0, 0], [0, 0, 3, 0, 0, 0], [7, 0, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0], [3, 0, 4, 0, 9, 0],
+              [0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0], [0, 5, 0, 7, 0, 9]]
+    cases += [list(m.f6_sqr(tuple(c))) for c in cases[:30]]
+    nsq = 0
+    for a in cases:
+        o = np.zeros(6, np.uint64)
+        ok = ha.ha_f6_sqrt(p_(arr(a)), p_(o))
+        ref = oracle.fp6_sqrt(a)
+        assert bool(ok) == (ref is not None), a
+        if ok:
+            nsq += 1
+            assert tuple(int(v) for v in oracle.fp6_sqr(o)) == tuple(a)
+    assert nsq >= 40
+    g = m.default_params().generator()
+    pts = [m.pt_mul(k, g) for k in (1, 2, 3, 99, m.Q - 1)] + [m.FIXTURE_SMALL_ORDER_PK] + list(m.SMALL_ORDER_POINTS.values())
+    enc = [m.pt_compress(p) for p in pts] + [m.pt_compress(None), bytes(49), b"\xff" * 49,
+                                              m.pt_compress(pts[0])[:48] + b"\xff", bytes(48) + b"\xc0",
+                                              bytes([1]) + bytes(47) + b"\x80", (2).to_bytes(8, "little") + bytes(41)]
+    enc += [bytes(c ^ (0x40 if i == 48 else 0) for i, c in enumerate(e)) for e in enc[:4]]
+    for e in enc:
+        o = np.zeros(12, np.uint64)
+        inf = C.c_int(0)
+        buf = np.frombuffer(e, np.uint8).copy()
+        st = ha.ha_decompress(buf.ctypes.data_as(C.c_void_p), p_(o), C.byref(inf))
+        want = oracle.decompress(e)
+        st_m, pt_m = m.pt_decompress(e)
+        assert (st == 0) == (want is not None) == (st_m == "ok"), e.hex()
+        if want is not None:
+            assert bool(inf.value) == want[1]
+            assert o.tobytes() == want[0]
