@@ -142,6 +142,29 @@ def main():
         torsion_rate = world * n * 2 / (time.perf_counter() - t2)
         total_fail_t = int(nfail.item())
 
+    # ---- the reference's own MSM-form verify_batch (one verdict per batch), 3 steps ----
+    msm = None
+    if not args.skip_torsion_leg:
+        coeffs = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device=dev, generator=g)
+        verdict = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def msm_step():
+            eng.verify_batch_msm_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, coeffs.data_ptr(),
+                                        16, verdict.data_ptr())
+        msm_step()
+        sync_all()
+        eng.enable_timing(True)
+        t3 = time.perf_counter()
+        for _ in range(3):
+            msm_step()
+        sync_all()
+        dt = time.perf_counter() - t3
+        eng.enable_timing(False)
+        stages = {k: eng.read_timing(k)[0] for k in ("ssa_k_hash", "msm_k_prepare", "msm_sort", "msm_k_buckets",
+                                                     "msm_reduce")}
+        msm = {"verifications_per_sec": world * n * 3 / dt, "ms_per_batch": dt / 3 * 1e3,
+               "verdict": int(verdict.item()), "expected_verdict": 2 if args.corrupt > 0 else 0, "stages_ms": stages}
+
     if rank == 0:
         value = world * n * args.steps / elapsed
         w_kernel = W_VERIFY_KERNEL
@@ -175,6 +198,7 @@ def main():
             "with_torsion_check_verifications_per_sec": torsion_rate,
             "with_torsion_check_rejected": total_fail_t,
             "kernels_ms": {"ssa_k_verify": k_verify_ms, "ssa_k_hash": k_hash_ms, "launches": k_cnt},
+            "verify_batch_msm_form": msm,
             "roofline": {
                 "bound": "valu-int64 (not hbm, not mfma: SURVEY.md 8(d))",
                 "kernel": "ssa_k_verify",

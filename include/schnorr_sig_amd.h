@@ -9,6 +9,8 @@
  *                               PublicKey::verify_signature src/signature.rs:170-176,
  *                               KeyedSignature::verify      src/signature.rs:232-234)
  *   ssa_verify_batch        <- verify_batch                 src/batch.rs:31-50
+ *   ssa_verify_batch_msm    <- verify_batch, the reference's own algorithm (random linear
+ *                              combination + 2n-point MSM)     src/batch.rs:56-130
  *   ssa_verify_many         <- n x Signature::verify (the per-signature accept/reject vector
  *                              BASELINE.json's north_star asks for)
  *   ssa_hash_message_many   <- hash_message                 src/signature.rs:274-306
@@ -111,6 +113,16 @@ int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, cons
                      const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
                      uint32_t flags);
 
+/* verify_batch exactly as src/batch.rs:31-130: sum s_i R_i - sum (s_i h_i) P_i ?= [sum s_i e_i] G with
+ * R_i decompressed from sig.x (flag byte honoured), a 2n-point bucket MSM on the GPU and an x-only
+ * comparison.  coeffs: n x 32-byte scalars standing in for Scalar::random(rng) (reduced mod q), or
+ * NULL for 128-bit coefficients drawn from getrandom(2).  Returns SSA_OK, SSA_INVALID_SIGNATURE, or
+ * SSA_MALFORMED where the reference panics (undecodable sig.x, src/batch.rs:67,104).  No torsion
+ * check, like the reference. */
+int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
+                         const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                         const uint8_t *coeffs);
+
 /* hash_message for n (R.x, pk, message) triples -> n x 32-byte digests */
 int ssa_hash_message_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks,
                           const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
@@ -152,6 +164,11 @@ int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_
                                 uint8_t *d_sigs_out);
 int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t n, uint8_t *d_pks_out,
                                uint8_t *d_pk_inf_out, uint8_t *d_status_out);
+/* coeff_bytes in 1..32: little-endian coefficient width; *d_verdict_out receives the status */
+int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
+                                const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
+                                size_t msg_len, size_t n, const uint8_t *d_coeffs, uint32_t coeff_bytes,
+                                uint32_t *d_verdict_out);
 int ssa_ctx_sync(ssa_ctx *ctx);
 
 /* ---- arithmetic probes (unit parity with the oracle; not part of the reference API) --- */

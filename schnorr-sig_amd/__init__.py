@@ -85,6 +85,8 @@ def _load():
         "ssa_hash_message_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
         "ssa_rescue_hash_many_device": (i32, [vp, vp, u32, sz, vp]),
         "ssa_keygen_sign_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, vp]),
+        "ssa_verify_batch_msm": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
+        "ssa_verify_batch_msm_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, u32, vp]),
         "ssa_decompress_many": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_decompress_many_device": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_debug_arith": (i32, [vp, i32, vp, vp, sz, sz, sz, vp, sz]),
@@ -186,6 +188,23 @@ class Engine:
         m, off, stride, mlen = self._msg_args(msgs, offsets, n)
         return _check(_lib.ssa_verify_batch(self._ctx, _ptr(sigs), _ptr(pks), _ptr(m), _ptr(off), stride, mlen,
                                             n, FLAG_CHECK_TORSION if check_torsion else 0), "ssa_verify_batch")
+
+    def verify_batch_msm(self, sigs, pks, msgs, offsets=None, coeffs=None):
+        """verify_batch as the reference runs it (random linear combination + MSM); one status."""
+        sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
+        n = sigs.shape[0]
+        if pks.shape[0] != n:
+            raise MalformedInput("We should have the same number of signatures than public keys")
+        m, off, stride, mlen = self._msg_args(msgs, offsets, n)
+        c = _np_u8(coeffs, 32) if coeffs is not None else None
+        return _check(_lib.ssa_verify_batch_msm(self._ctx, _ptr(sigs), _ptr(pks), _ptr(m), _ptr(off), stride, mlen,
+                                                n, _ptr(c)), "ssa_verify_batch_msm")
+
+    def verify_batch_msm_device(self, d_sigs, d_pks, d_msgs, n, msg_len, d_coeffs, coeff_bytes, d_verdict,
+                                msg_stride=None, d_offsets=0):
+        _check(_lib.ssa_verify_batch_msm_device(self._ctx, d_sigs, d_pks, d_msgs, d_offsets or None,
+                                                msg_stride if msg_stride is not None else msg_len, msg_len, n,
+                                                d_coeffs, coeff_bytes, d_verdict), "ssa_verify_batch_msm_device")
 
     def verify_one(self, sig81, pk96, message, check_torsion=True):
         sig, pk = _np_u8(bytearray(sig81)), _np_u8(bytearray(pk96))
@@ -427,10 +446,11 @@ class KeyPair:
         return signature.verify(message, self.public_key)
 
 
-def verify_batch(signatures, public_keys, messages, rng=None, engine=None):
+def verify_batch(signatures, public_keys, messages, rng=None, engine=None, msm=False):
     """verify_batch (src/batch.rs:31-50): Ok -> None, else raises SignatureError.
-    `rng` is accepted for signature compatibility and unused: the engine checks every
-    signature exactly instead of a random linear combination (divergence classes)."""
+    msm=False: AND of exact per-signature checks (`rng` unused; DESIGN.md, divergence classes).
+    msm=True: the reference's own algorithm on the GPU -- random linear combination (coefficients from
+    `rng(32)` per signature, or getrandom when rng is None) and a 2n-point MSM."""
     if len(signatures) != len(public_keys):
         raise MalformedInput("We should have the same number of signatures than public keys")
     if len(messages) != len(public_keys):
@@ -441,7 +461,14 @@ def verify_batch(signatures, public_keys, messages, rng=None, engine=None):
     sigs = np.frombuffer(b"".join(s.bytes for s in signatures), np.uint8)
     pks = np.frombuffer(b"".join(p.affine for p in public_keys), np.uint8)
     flat, off = pack_messages(messages)
-    st = eng.verify_batch_status(sigs, pks, flat, offsets=off, check_torsion=False)
+    if msm:
+        coeffs = None
+        if rng is not None:
+            coeffs = np.frombuffer(b"".join((int.from_bytes(rng(64), "little") % Q).to_bytes(32, "little")
+                                            for _ in signatures), np.uint8)
+        st = eng.verify_batch_msm(sigs, pks, flat, offsets=off, coeffs=coeffs)
+    else:
+        st = eng.verify_batch_status(sigs, pks, flat, offsets=off, check_torsion=False)
     if st == OK:
         return None
     if st == MALFORMED:

@@ -21,7 +21,7 @@ typedef unsigned int u32;
 #define SSA_DEV __host__ __device__ __forceinline__
 // out-of-line: the Fp6 product/square bodies are ~4 KB each; one copy keeps the scalar-
 // multiplication loop inside the 64 KB instruction cache.
-#define SSA_FN __host__ __device__ __attribute__((noinline))
+#define SSA_FN inline __host__ __device__ __attribute__((noinline))
 
 constexpr u64 FP_P = 0xffffffff00000001ULL;
 constexpr u32 FP_EPS = 0xffffffffu;

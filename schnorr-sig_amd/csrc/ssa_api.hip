@@ -1,91 +1,12 @@
 // C ABI (include/schnorr_sig_amd.h) over the HIP kernels in ssa_kernels.cuh.
 // No CPU compute path exists here: every entry point launches kernels on the context's
 // device or fails with an SSA_ERR_* code.
-#include "../../include/schnorr_sig_amd.h"
-#include "ssa_kernels.cuh"
-
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-using namespace ssa;
+#define SSA_KERNELS_DEFINE 1
+#include "ssa_ctx.hpp"
 
 static const unsigned char k_default_params[SSA_PARAMS_LENGTH] = {
 #include "../params/params_default.inc"
 };
-
-#define HIP_TRY(expr)                                                                    \
-    do {                                                                                 \
-        hipError_t err__ = (expr);                                                       \
-        if (err__ != hipSuccess) {                                                       \
-            std::fprintf(stderr, "[schnorr_sig_amd] %s failed: %s (%s:%d)\n", #expr,     \
-                         hipGetErrorString(err__), __FILE__, __LINE__);                  \
-            return SSA_ERR_HIP;                                                          \
-        }                                                                                \
-    } while (0)
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) return SSA_ERR_HIP;
-        cap = want;
-        return 0;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-struct TimedLaunch {
-    hipEvent_t start, stop;
-};
-
-struct ssa_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    DevParams *d_params = nullptr;
-    u64 *d_gtab = nullptr;
-    DevBuf ws_h, ws_tab, ws_fail;
-    // staging for the host-buffer entry points
-    DevBuf st_sigs, st_pks, st_inf, st_msgs, st_off, st_status, st_aux, st_aux2;
-    bool timing = false;
-    unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
-    std::map<std::string, std::vector<TimedLaunch>> timed;
-};
-
-static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
-
-template <class F>
-static int timed_launch(ssa_ctx *ctx, const char *name, F &&launch) {
-    if (!ctx->timing) {
-        launch();
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    TimedLaunch t;
-    HIP_TRY(hipEventCreate(&t.start));
-    HIP_TRY(hipEventCreate(&t.stop));
-    HIP_TRY(hipEventRecord(t.start, ctx->stream));
-    launch();
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(t.stop, ctx->stream));
-    ctx->timed[name].push_back(t);
-    return 0;
-}
 
 extern "C" const char *ssa_strerror(int rc) {
     switch (rc) {
@@ -183,7 +104,10 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
             (void)hipEventDestroy(t.stop);
         }
     for (DevBuf *b : {&ctx->ws_h, &ctx->ws_tab, &ctx->ws_fail, &ctx->st_sigs, &ctx->st_pks, &ctx->st_inf,
-                      &ctx->st_msgs, &ctx->st_off, &ctx->st_status, &ctx->st_aux, &ctx->st_aux2})
+                      &ctx->st_msgs, &ctx->st_off, &ctx->st_status, &ctx->st_aux, &ctx->st_aux2, &ctx->msm_points,
+                      &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
+                      &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
+                      &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
@@ -234,14 +158,6 @@ extern "C" int ssa_ctx_read_timing(ssa_ctx *ctx, const char *kernel, double *avg
 }
 
 // ------------------------------------------------------------------ device entry points
-static int check_msgs(const uint8_t *msgs, const uint64_t *off, size_t stride, size_t len, size_t n) {
-    if (n == 0) return 0;
-    if (!off && len > 0 && !msgs) return SSA_ERR_ARG;
-    if (!off && stride < len) return SSA_ERR_ARG;
-    if (len > 0xffffffffull) return SSA_ERR_ARG;
-    return 0;
-}
-
 extern "C" int ssa_hash_message_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
                                             const uint8_t *d_msgs, const uint64_t *d_msg_off,
                                             size_t msg_stride, size_t msg_len, size_t n,
@@ -265,6 +181,16 @@ extern "C" int ssa_rescue_hash_many_device(ssa_ctx *ctx, const uint64_t *d_felts
     return timed_launch(ctx, "ssa_k_rescue", [&] {
         hipLaunchKernelGGL(ssa_k_rescue, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
                            (const u64 *)d_felts, felts_per_row, n, (u64 *)d_digests_out);
+    });
+}
+
+int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
+                              const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n) {
+    if (ctx->ws_h.reserve(n * 4 * sizeof(u64))) return SSA_ERR_HIP;
+    MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
+    return timed_launch(ctx, "ssa_k_hash", [&] {
+        hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                           d_sigs, d_pks, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr);
     });
 }
 
@@ -322,47 +248,6 @@ extern "C" int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compres
 }
 
 // ------------------------------------------------------------------ host entry points
-static size_t msgs_bytes(const uint64_t *off, size_t stride, size_t len, size_t n) {
-    if (n == 0) return 0;
-    if (off) return (size_t)off[n];
-    return (n - 1) * stride + len;
-}
-
-struct StagedInputs {
-    const u8 *sigs = nullptr, *pks = nullptr, *inf = nullptr, *msgs = nullptr;
-    const u64 *off = nullptr;
-};
-
-static int stage_up(ssa_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, const void **dst) {
-    *dst = nullptr;
-    if (!src || bytes == 0) {
-        if (buf.reserve(16)) return SSA_ERR_HIP;  // non-null dummy for zero-length messages
-        *dst = src ? buf.p : nullptr;
-        return 0;
-    }
-    if (buf.reserve(bytes)) return SSA_ERR_HIP;
-    HIP_TRY(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    *dst = buf.p;
-    return 0;
-}
-
-static int stage_msgs(ssa_ctx *ctx, const uint8_t *msgs, const uint64_t *off, size_t stride, size_t len,
-                      size_t n, StagedInputs &s) {
-    const void *p;
-    if (off) {
-        for (size_t i = 0; i < n; i++)
-            if (off[i + 1] < off[i] || off[i + 1] - off[i] > 0xffffffffull) return SSA_ERR_ARG;
-        if (int rc = stage_up(ctx, ctx->st_off, off, (n + 1) * sizeof(uint64_t), &p)) return rc;
-        s.off = (const u64 *)p;
-    }
-    const size_t mb = msgs_bytes(off, stride, len, n);
-    if (mb && !msgs) return SSA_ERR_ARG;
-    if (ctx->st_msgs.reserve(mb + 16)) return SSA_ERR_HIP;
-    if (mb) HIP_TRY(hipMemcpyAsync(ctx->st_msgs.p, msgs, mb, hipMemcpyHostToDevice, ctx->stream));
-    s.msgs = (const u8 *)ctx->st_msgs.p;
-    return 0;
-}
-
 extern "C" int ssa_verify_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                                const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
                                size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,

@@ -1,0 +1,143 @@
+// Internal: context layout and helpers shared by the translation units of the library
+// (ssa_api.hip: per-lane verification path; ssa_msm.hip: MSM-form batch verification).
+#pragma once
+#include "../../include/schnorr_sig_amd.h"
+#include "ssa_kernels.cuh"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ssa;
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t err__ = (expr);                                                       \
+        if (err__ != hipSuccess) {                                                       \
+            std::fprintf(stderr, "[schnorr_sig_amd] %s failed: %s (%s:%d)\n", #expr,     \
+                         hipGetErrorString(err__), __FILE__, __LINE__);                  \
+            return SSA_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) return SSA_ERR_HIP;
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+};
+
+struct ssa_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    DevParams *d_params = nullptr;
+    u64 *d_gtab = nullptr;
+    DevBuf ws_h, ws_tab, ws_fail;
+    // staging for the host-buffer entry points
+    DevBuf st_sigs, st_pks, st_inf, st_msgs, st_off, st_status, st_aux, st_aux2;
+    // MSM-form batch verification (ssa_msm.hip)
+    DevBuf msm_points, msm_scalars, msm_keys, msm_vals, msm_keys2, msm_vals2, msm_sort_tmp, msm_bounds,
+        msm_buckets, msm_chunks, msm_windows, msm_partials, msm_flags, st_coeffs;
+    bool timing = false;
+    unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
+    std::map<std::string, std::vector<TimedLaunch>> timed;
+};
+
+static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+template <class F>
+static inline int timed_launch(ssa_ctx *ctx, const char *name, F &&launch) {
+    if (!ctx->timing) {
+        launch();
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    TimedLaunch t;
+    HIP_TRY(hipEventCreate(&t.start));
+    HIP_TRY(hipEventCreate(&t.stop));
+    HIP_TRY(hipEventRecord(t.start, ctx->stream));
+    launch();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(t.stop, ctx->stream));
+    ctx->timed[name].push_back(t);
+    return 0;
+}
+
+
+// ---- argument checks and host->device staging shared by the entry points ----
+static inline int check_msgs(const uint8_t *msgs, const uint64_t *off, size_t stride, size_t len, size_t n) {
+    if (n == 0) return 0;
+    if (!off && len > 0 && !msgs) return SSA_ERR_ARG;
+    if (!off && stride < len) return SSA_ERR_ARG;
+    if (len > 0xffffffffull) return SSA_ERR_ARG;
+    return 0;
+}
+
+static inline size_t msgs_bytes(const uint64_t *off, size_t stride, size_t len, size_t n) {
+    if (n == 0) return 0;
+    if (off) return (size_t)off[n];
+    return (n - 1) * stride + len;
+}
+
+struct StagedInputs {
+    const u8 *sigs = nullptr, *pks = nullptr, *inf = nullptr, *msgs = nullptr;
+    const u64 *off = nullptr;
+};
+
+static inline int stage_up(ssa_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, const void **dst) {
+    *dst = nullptr;
+    if (!src || bytes == 0) {
+        if (buf.reserve(16)) return SSA_ERR_HIP;  // non-null dummy for zero-length messages
+        *dst = src ? buf.p : nullptr;
+        return 0;
+    }
+    if (buf.reserve(bytes)) return SSA_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dst = buf.p;
+    return 0;
+}
+
+static inline int stage_msgs(ssa_ctx *ctx, const uint8_t *msgs, const uint64_t *off, size_t stride, size_t len,
+                      size_t n, StagedInputs &s) {
+    const void *p;
+    if (off) {
+        for (size_t i = 0; i < n; i++)
+            if (off[i + 1] < off[i] || off[i + 1] - off[i] > 0xffffffffull) return SSA_ERR_ARG;
+        if (int rc = stage_up(ctx, ctx->st_off, off, (n + 1) * sizeof(uint64_t), &p)) return rc;
+        s.off = (const u64 *)p;
+    }
+    const size_t mb = msgs_bytes(off, stride, len, n);
+    if (mb && !msgs) return SSA_ERR_ARG;
+    if (ctx->st_msgs.reserve(mb + 16)) return SSA_ERR_HIP;
+    if (mb) HIP_TRY(hipMemcpyAsync(ctx->st_msgs.p, msgs, mb, hipMemcpyHostToDevice, ctx->stream));
+    s.msgs = (const u8 *)ctx->st_msgs.p;
+    return 0;
+}
+
+
+// defined in ssa_api.hip: hash_message + Scalar::from_bits_vartime for n signatures into ctx->ws_h
+int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
+                              const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n);

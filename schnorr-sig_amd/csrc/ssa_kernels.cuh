@@ -116,7 +116,7 @@ SSA_DEV void hash_message_lane(u64 *A, u64 *B, const DevParams *__restrict__ prm
 }
 
 // ------------------------------------------------------------------------------------------
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
 ssa_k_hash(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs,
            const u8 *__restrict__ pks, MsgView mv, size_t n, u64 *__restrict__ h_out,
@@ -146,9 +146,9 @@ ssa_k_hash(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs,
         for (int k = 0; k < 4; k++) h_out[4 * i + k] = h.w[k];
     }
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
 ssa_k_rescue(const DevParams *__restrict__ prm, const u64 *__restrict__ felts, u32 per_row,
              size_t n, u64 *__restrict__ out) {
@@ -162,7 +162,7 @@ ssa_k_rescue(const DevParams *__restrict__ prm, const u64 *__restrict__ felts, u
 #pragma unroll
     for (int k = 0; k < 4; k++) out[4 * i + k] = d[k];
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 // ------------------------------------------------------------------------------------------
 // per-lane table rows
@@ -318,7 +318,7 @@ SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e) 
     return acc;
 }
 
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256, 2)
 ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
              const u8 *__restrict__ pk_inf, const u64 *__restrict__ h_in,
@@ -377,11 +377,11 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
     const unsigned long long bad = __ballot(status != ST_OK);
     if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(n_fail, (unsigned long long)__popcll(bad));
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 // ------------------------------------------------------------------------------------------
 // gtab[w][d] = affine [d * 2^(16 w)] G, d = 1..65535 (d = 0 rows stay zero and are never read)
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
 ssa_k_gtable(const DevParams *__restrict__ prm, u64 *__restrict__ gtab) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -409,7 +409,7 @@ ssa_k_gtable(const DevParams *__restrict__ prm, u64 *__restrict__ gtab) {
         q[3 + i] = make_ulonglong2(a.y.c[2 * i], a.y.c[2 * i + 1]);
     }
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 // ------------------------------------------------------------------------------------------
 // scalar arithmetic mod q for signing (e = r - sk*h, src/signature.rs:124)
@@ -472,7 +472,7 @@ SSA_DEV sc256 sc_mul_mod(const sc256 &a, const sc256 &b) {
     return r;
 }
 
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
 ssa_k_sign(const DevParams *__restrict__ prm, const u64 *__restrict__ gtab,
            const u8 *__restrict__ sks, const u8 *__restrict__ nonces, MsgView mv, size_t n,
@@ -505,7 +505,7 @@ ssa_k_sign(const DevParams *__restrict__ prm, const u64 *__restrict__ gtab,
 #pragma unroll
     for (int k = 0; k < 4; k++) st_u64_le(sig + 49 + 8 * k, e.w[k]);
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 // ------------------------------------------------------------------------------------------
 // AffinePoint::from_compressed: 48 bytes of x || flag byte (bit 7 infinity, bit 6 sort flag, other
@@ -537,7 +537,7 @@ SSA_DEV u32 decompress_lane(const u8 *__restrict__ c, aff &out, bool &is_inf) {
     return 0;
 }
 
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
 ssa_k_decompress(const u8 *__restrict__ comp, size_t n, u8 *__restrict__ pks_out, u8 *__restrict__ inf_out,
                  u8 *__restrict__ status_out) {
@@ -551,11 +551,11 @@ ssa_k_decompress(const u8 *__restrict__ comp, size_t n, u8 *__restrict__ pks_out
     if (inf_out) inf_out[i] = inf ? 1 : 0;
     status_out[i] = (u8)st;
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 // ------------------------------------------------------------------------------------------
 // arithmetic probes (ssa_debug_arith)
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
                             size_t as, size_t bs, u64 *__restrict__ out, size_t os) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -607,10 +607,10 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
         return;
     }
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 // [k]P with the production table code path (op 4): a = k (4 u64), b = P (12 u64 + inf)
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void ssa_k_debug_mul(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
                                 size_t as, size_t bs, u64 *__restrict__ ws_tab,
                                 u64 *__restrict__ out, size_t os) {
@@ -638,10 +638,10 @@ __global__ void ssa_k_debug_mul(const u64 *__restrict__ a, const u64 *__restrict
     }
     po[12] = jac_is_identity(r) ? 1 : 0;
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 // register-resident Fp-mul throughput probe: each lane runs ILP independent multiply chains
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 template <int ILP>
 __global__ void __launch_bounds__(256) ssa_k_fpmul_bench(u64 *out, u64 seed, int iters) {
     u64 x[ILP], y[ILP];
@@ -663,10 +663,10 @@ __global__ void __launch_bounds__(256) ssa_k_fpmul_bench(u64 *out, u64 seed, int
     for (int j = 0; j < ILP; j++) acc ^= x[j] ^ y[j];
     out[t] = acc;
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 // same probe through the lazy Fp6 product (36 products + 6 reductions per f6_mul)
-#ifndef SSA_HOST_TEST
+#ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256) ssa_k_f6mul_bench(u64 *out, u64 seed, int iters) {
     fp6 x, y;
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -685,6 +685,6 @@ __global__ void __launch_bounds__(256) ssa_k_f6mul_bench(u64 *out, u64 seed, int
     for (int j = 0; j < 6; j++) acc ^= x.c[j] ^ y.c[j];
     out[t] = acc;
 }
-#endif  // SSA_HOST_TEST
+#endif  // SSA_NO_KERNELS
 
 }  // namespace ssa

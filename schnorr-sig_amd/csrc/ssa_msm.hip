@@ -1,0 +1,365 @@
+// MSM-form batch verification on the GPU: the algorithm the reference's verify_batch actually runs
+// (src/batch.rs:31-130).
+//
+//     sum_i s_i R_i  -  sum_i (s_i h_i) P_i   ?=   [ sum_i s_i e_i ] G        (x-only comparison)
+//
+// with R_i decompressed from sig.x (src/batch.rs:104), h_i = hash_message scalars (:64-73), s_i the
+// random coefficients (:75-78).  The 2n-point multi-scalar multiplication is a bucket method laid out
+// for the GPU:
+//   1. msm_k_prepare   per signature: decompress R, form the points R_i, -P_i and the scalars
+//                      a_i = s_i, b_i = s_i h_i mod q, and block-reduce s_i e_i mod q
+//   2. msm_k_digits    (window, digit) sort keys for every point; hipCUB radix sort groups the point
+//                      indices of each bucket; msm_k_bounds finds the bucket extents
+//   3. msm_k_buckets   ONE BUCKET PER LANE: a lane adds up the points of its bucket with mixed
+//                      additions (every exceptional case handled: equal public keys land in one bucket)
+//   4. msm_k_chunks    running-sum trick on chunks of 64 buckets; msm_k_windows sums the chunks of a
+//                      window and shifts it by 2^(c j); msm_k_finish adds the windows, computes
+//                      [lin]G from the comb table and compares the x coordinates
+// Panics of the reference (undecodable x, x not on the curve: src/batch.rs:67,104) give SSA_MALFORMED.
+#define SSA_NO_KERNELS 1
+#include "ssa_ctx.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include <sys/random.h>
+
+namespace ssa {
+
+constexpr int MSM_CHUNK = 64;  // buckets per lane in the running-sum pass
+
+struct MsmShape {
+    u32 c;        // window bits
+    u32 windows;  // ceil(255 / c)
+    u32 buckets;  // 2^c
+    u32 chunks;   // per window
+};
+
+SSA_DEV u32 sc_window(const u64 *__restrict__ k, u32 bit, u32 c) {
+    const u32 wi = bit >> 6, sh = bit & 63u;
+    u64 v = k[wi] >> sh;
+    if (sh + c > 64 && wi < 3) v |= k[wi + 1] << (64 - sh);
+    return (u32)(v & ((1ull << c) - 1ull));
+}
+
+SSA_DEV void st_aff_row(u64 *__restrict__ row, const aff &p) {
+    st_f6(row, p.x);
+    st_f6(row + 6, p.y);
+}
+
+// ---- 1. points and scalars ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u64 *__restrict__ h_in,
+              const u8 *__restrict__ coeffs, u32 coeff_bytes, size_t n, u64 *__restrict__ points,
+              u64 *__restrict__ scalars, u64 *__restrict__ partials, u32 *__restrict__ malformed) {
+    __shared__ u64 red[256 * 4];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    sc256 se;
+#pragma unroll
+    for (int k = 0; k < 4; k++) se.w[k] = 0;
+    if (i < n) {
+        bool ok = true;
+        aff P;
+        P.x = ld_fp6(pks + 96 * i, ok);
+        P.y = ld_fp6(pks + 96 * i + 48, ok);
+        const sc256 e = ld_sc(sigs + 81 * i + 49);
+        ok = ok && !sc_geq_q(e);
+        if (ok) ok = aff_on_curve(P);
+        aff R;
+        bool r_inf = false;
+        if (ok) ok = decompress_lane(sigs + 81 * i, R, r_inf) == 0;   // from_compressed(..).unwrap(), :104
+        if (!ok) {
+            atomicOr(malformed, 1u);
+            R.x = f6_zero(); R.y = f6_zero();
+            P.x = f6_zero(); P.y = f6_zero();
+        }
+        if (r_inf) {  // identity R: the (0, 0) sentinel jac_madd skips
+            R.x = f6_zero();
+            R.y = f6_zero();
+        }
+        sc256 s;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s.w[k] = 0;
+        const u8 *cp = coeffs + (size_t)coeff_bytes * i;
+        for (u32 b = 0; b < coeff_bytes; b++) s.w[b >> 3] |= (u64)cp[b] << (8 * (b & 7u));
+        s = sc_reduce256(s);                                           // Scalar::random, :75-78
+        sc256 h;
+#pragma unroll
+        for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
+        const sc256 sh = sc_mul_mod(s, h);                             // hashes[i] *= scalars[i], :109-111
+        if (ok) se = sc_mul_mod(s, e);                                 // s * e, :92-97
+        P.y = f6_canon(f6_neg(P.y));                                   // k.0.neg(), :106
+        st_aff_row(points + 12 * i, R);
+        st_aff_row(points + 12 * (n + i), P);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            scalars[4 * i + k] = s.w[k];
+            scalars[4 * (n + i) + k] = sh.w[k];
+        }
+    }
+    // block reduction of s_i e_i mod q
+#pragma unroll
+    for (int k = 0; k < 4; k++) red[threadIdx.x * 4 + k] = se.w[k];
+    __syncthreads();
+    for (u32 stride = 128; stride > 0; stride >>= 1) {
+        if (threadIdx.x < stride) {
+            sc256 a, b;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                a.w[k] = red[threadIdx.x * 4 + k];
+                b.w[k] = red[(threadIdx.x + stride) * 4 + k];
+            }
+            a = sc_add_mod(a, b);
+#pragma unroll
+            for (int k = 0; k < 4; k++) red[threadIdx.x * 4 + k] = a.w[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) partials[4 * blockIdx.x + k] = red[k];
+    }
+}
+
+// ---- 2. sort keys ------------------------------------------------------------------------------
+__global__ void msm_k_digits(const u64 *__restrict__ scalars, size_t npts, MsmShape sh,
+                             u32 *__restrict__ keys, u32 *__restrict__ vals) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npts * sh.windows) return;
+    const u32 j = (u32)(t / npts);
+    const size_t i = t - (size_t)j * npts;
+    const u32 d = sc_window(scalars + 4 * i, j * sh.c, sh.c);
+    keys[t] = j * sh.buckets + d;
+    vals[t] = (u32)i;
+}
+
+// bounds[2*key] = first position, bounds[2*key+1] = one past the last (both 0 for empty buckets)
+__global__ void msm_k_bounds(const u32 *__restrict__ keys, size_t total, u32 *__restrict__ bounds) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const u32 k = keys[t];
+    if (t == 0 || keys[t - 1] != k) bounds[2 * (size_t)k] = (u32)t;
+    if (t + 1 == total || keys[t + 1] != k) bounds[2 * (size_t)k + 1] = (u32)(t + 1);
+}
+
+// ---- 3. one bucket per lane ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+msm_k_buckets(const u64 *__restrict__ points, const u32 *__restrict__ vals, const u32 *__restrict__ bounds,
+              MsmShape sh, u64 *__restrict__ bsum) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nb = (size_t)sh.windows * sh.buckets;
+    if (t >= nb) return;
+    jac acc = jac_identity();
+    if ((t & (sh.buckets - 1)) != 0) {   // digit 0 contributes nothing
+        const u32 lo = bounds[2 * t], hi = bounds[2 * t + 1];
+#pragma unroll 1
+        for (u32 p = lo; p < hi; p++) {
+            const aff q = ld_aff(points + 12 * (size_t)vals[p]);
+            acc = jac_madd(acc, q);
+        }
+    }
+    st_jac(bsum + 18 * t, acc);
+}
+
+// ---- 4. bucket reduction ------------------------------------------------------------------------
+// chunk of MSM_CHUNK buckets [v0, v0 + L): sum_v v B_v = sum_v (v - v0 + 1) B_v + (v0 - 1) sum_v B_v
+__global__ void __launch_bounds__(256, 2)
+msm_k_chunks(const u64 *__restrict__ bsum, MsmShape sh, u64 *__restrict__ chunk_out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)sh.windows * sh.chunks) return;
+    const u32 j = (u32)(t / sh.chunks), ch = (u32)(t % sh.chunks);
+    const u32 len = sh.buckets < (u32)MSM_CHUNK ? sh.buckets : (u32)MSM_CHUNK;
+    const u32 v0 = ch * len;
+    jac running = jac_identity(), total = jac_identity();
+#pragma unroll 1
+    for (int v = (int)(v0 + len) - 1; v >= (int)v0; v--) {
+        if (v == 0) break;
+        const jac b = ld_jac(bsum + 18 * ((size_t)j * sh.buckets + (u32)v));
+        running = jac_add(running, b);
+        total = jac_add(total, running);
+    }
+    // + [v0 - 1] running (v0 >= 1 here unless this is the first chunk, where the weight offset is 0)
+    if (v0 > 1) {
+        const u32 m = v0 - 1;
+        jac acc = jac_identity();
+#pragma unroll 1
+        for (int bit = 15; bit >= 0; bit--) {
+            acc = jac_dbl(acc);
+            if ((m >> bit) & 1u) acc = jac_add(acc, running);
+        }
+        total = jac_add(total, acc);
+    }
+    st_jac(chunk_out + 18 * t, total);
+}
+
+// window j: W_j = sum of its chunks, shifted by 2^(c j)
+__global__ void __launch_bounds__(64, 2)
+msm_k_windows(const u64 *__restrict__ chunk_in, MsmShape sh, u64 *__restrict__ win_out) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= sh.windows) return;
+    jac acc = jac_identity();
+#pragma unroll 1
+    for (u32 ch = 0; ch < sh.chunks; ch++) acc = jac_add(acc, ld_jac(chunk_in + 18 * ((size_t)j * sh.chunks + ch)));
+#pragma unroll 1
+    for (u32 s = 0; s < j * sh.c; s++) acc = jac_dbl(acc);
+    st_jac(win_out + 18 * (size_t)j, acc);
+}
+
+// left = sum_j W_j ; right = [lin] G ; verdict: x-only comparison (src/batch.rs:125-129)
+__global__ void __launch_bounds__(64, 2)
+msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict__ partials, u32 n_partials,
+             const u64 *__restrict__ gtab, const u32 *__restrict__ malformed, u32 *__restrict__ verdict) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (*malformed) {
+        *verdict = ST_MALFORMED;
+        return;
+    }
+    jac left = jac_identity();
+#pragma unroll 1
+    for (u32 j = 0; j < sh.windows; j++) left = jac_add(left, ld_jac(win_in + 18 * (size_t)j));
+    sc256 lin;
+#pragma unroll
+    for (int k = 0; k < 4; k++) lin.w[k] = 0;
+#pragma unroll 1
+    for (u32 b = 0; b < n_partials; b++) {
+        sc256 p;
+#pragma unroll
+        for (int k = 0; k < 4; k++) p.w[k] = partials[4 * b + k];
+        lin = sc_add_mod(lin, p);
+    }
+    const jac right = add_base_mul(jac_identity(), gtab, lin);     // BASEPOINT_TABLE.multiply_vartime, :98-100
+    // left.get_x() == scaled_basepoint.get_x(): X_l Z_r^2 == X_r Z_l^2; the identity's x is taken as 0
+    const bool li = jac_is_identity(left), ri = jac_is_identity(right);
+    bool eq;
+    if (li || ri) {
+        eq = (li && ri) || (li && f6_is_zero(right.X)) || (ri && f6_is_zero(left.X));
+    } else {
+        eq = f6_eq(f6_mul(left.X, f6_sqr(right.Z)), f6_mul(right.X, f6_sqr(left.Z)));
+    }
+    *verdict = eq ? ST_OK : ST_INVALID_SIG;
+}
+
+}  // namespace ssa
+
+// ------------------------------------------------------------------------------------------------
+static MsmShape msm_shape(size_t n) {
+    // mean bucket occupancy 2n / 2^c of about 32 keeps the one-bucket-per-lane pass balanced
+    size_t pts = 2 * n;
+    u32 lg = 0;
+    while ((1ull << (lg + 1)) <= pts) lg++;
+    int c = (int)lg - 5;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    MsmShape sh;
+    sh.c = (u32)c;
+    sh.windows = (255 + sh.c - 1) / sh.c;
+    sh.buckets = 1u << sh.c;
+    sh.chunks = sh.buckets <= (u32)MSM_CHUNK ? 1u : sh.buckets / (u32)MSM_CHUNK;
+    return sh;
+}
+
+extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
+                                           const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
+                                           size_t msg_len, size_t n, const uint8_t *d_coeffs, uint32_t coeff_bytes,
+                                           uint32_t *d_verdict_out) {
+    if (!ctx || !d_verdict_out) return SSA_ERR_ARG;
+    if (n && (!d_sigs || !d_pks || !d_coeffs)) return SSA_ERR_ARG;
+    if (coeff_bytes == 0 || coeff_bytes > 32) return SSA_ERR_ARG;
+    if (n > (1ull << 27)) return SSA_ERR_ARG;   // 32-bit sort positions
+    if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) {   // empty batch: Ok (src/batch.rs)
+        HIP_TRY(hipMemsetAsync(d_verdict_out, 0, sizeof(uint32_t), ctx->stream));
+        return 0;
+    }
+    const MsmShape sh = msm_shape(n);
+    const size_t npts = 2 * n, total = npts * sh.windows, nb = (size_t)sh.windows * sh.buckets;
+    const unsigned n_blocks = grid_for(n, 256);
+    size_t sort_tmp = 0;
+    const int end_bit = 32 - __builtin_clz((unsigned)(nb - 1) | 1u);
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const u32 *)nullptr, (u32 *)nullptr,
+                                           (const u32 *)nullptr, (u32 *)nullptr, (int)total, 0, end_bit,
+                                           ctx->stream) != hipSuccess)
+        return SSA_ERR_HIP;
+    if (ctx->ws_h.reserve(n * 32) || ctx->msm_points.reserve(npts * 96) || ctx->msm_scalars.reserve(npts * 32) ||
+        ctx->msm_keys.reserve(total * 4) || ctx->msm_vals.reserve(total * 4) || ctx->msm_keys2.reserve(total * 4) ||
+        ctx->msm_vals2.reserve(total * 4) || ctx->msm_sort_tmp.reserve(sort_tmp + 16) ||
+        ctx->msm_bounds.reserve(nb * 8) || ctx->msm_buckets.reserve(nb * 144) ||
+        ctx->msm_chunks.reserve((size_t)sh.windows * sh.chunks * 144) || ctx->msm_windows.reserve(sh.windows * 144) ||
+        ctx->msm_partials.reserve((size_t)n_blocks * 32) || ctx->msm_flags.reserve(64))
+        return SSA_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->msm_bounds.p, 0, nb * 8, ctx->stream));
+    // challenge scalars h_i with the kernel of the per-lane path
+    if (int rc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+    int rc = timed_launch(ctx, "msm_k_prepare", [&] {
+        hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, ctx->stream, d_sigs, d_pks,
+                           (const u64 *)ctx->ws_h.p, d_coeffs, coeff_bytes, n, (u64 *)ctx->msm_points.p,
+                           (u64 *)ctx->msm_scalars.p, (u64 *)ctx->msm_partials.p, (u32 *)ctx->msm_flags.p);
+    });
+    if (rc) return rc;
+    rc = timed_launch(ctx, "msm_sort", [&] {
+        hipLaunchKernelGGL(msm_k_digits, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)ctx->msm_scalars.p, npts, sh, (u32 *)ctx->msm_keys.p, (u32 *)ctx->msm_vals.p);
+        (void)hipcub::DeviceRadixSort::SortPairs(ctx->msm_sort_tmp.p, sort_tmp, (const u32 *)ctx->msm_keys.p,
+                                                 (u32 *)ctx->msm_keys2.p, (const u32 *)ctx->msm_vals.p,
+                                                 (u32 *)ctx->msm_vals2.p, (int)total, 0, end_bit, ctx->stream);
+        hipLaunchKernelGGL(msm_k_bounds, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream,
+                           (const u32 *)ctx->msm_keys2.p, total, (u32 *)ctx->msm_bounds.p);
+    });
+    if (rc) return rc;
+    rc = timed_launch(ctx, "msm_k_buckets", [&] {
+        hipLaunchKernelGGL(msm_k_buckets, dim3(grid_for(nb, 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)ctx->msm_points.p, (const u32 *)ctx->msm_vals2.p,
+                           (const u32 *)ctx->msm_bounds.p, sh, (u64 *)ctx->msm_buckets.p);
+    });
+    if (rc) return rc;
+    return timed_launch(ctx, "msm_reduce", [&] {
+        hipLaunchKernelGGL(msm_k_chunks, dim3(grid_for((size_t)sh.windows * sh.chunks, 256)), dim3(256), 0,
+                           ctx->stream, (const u64 *)ctx->msm_buckets.p, sh, (u64 *)ctx->msm_chunks.p);
+        hipLaunchKernelGGL(msm_k_windows, dim3(grid_for(sh.windows, 64)), dim3(64), 0, ctx->stream,
+                           (const u64 *)ctx->msm_chunks.p, sh, (u64 *)ctx->msm_windows.p);
+        hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)ctx->msm_windows.p, sh,
+                           (const u64 *)ctx->msm_partials.p, n_blocks, (const u64 *)ctx->d_gtab,
+                           (const u32 *)ctx->msm_flags.p, d_verdict_out);
+    });
+}
+
+extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
+                                    const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                                    const uint8_t *coeffs) {
+    if (!ctx || (n && (!sigs || !pks))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (n == 0) return SSA_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // Scalar::random(rng) (src/batch.rs:75-78): caller-supplied 32-byte scalars, or 128-bit
+    // coefficients from the kernel's CSPRNG (getrandom) when coeffs == NULL
+    std::vector<uint8_t> own;
+    uint32_t cb = 32;
+    if (!coeffs) {
+        cb = 16;
+        own.resize(n * 16);
+        size_t got = 0;
+        while (got < own.size()) {
+            ssize_t r = getrandom(own.data() + got, own.size() - got, 0);
+            if (r <= 0) return SSA_ERR_ARG;
+            got += (size_t)r;
+        }
+        coeffs = own.data();
+    }
+    StagedInputs s;
+    const void *p;
+    if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;
+    s.sigs = (const u8 *)p;
+    if (int rc = stage_up(ctx, ctx->st_pks, pks, n * 96, &p)) return rc;
+    s.pks = (const u8 *)p;
+    if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
+    if (int rc = stage_up(ctx, ctx->st_coeffs, coeffs, n * cb, &p)) return rc;
+    uint32_t *d_verdict = (uint32_t *)((char *)ctx->ws_fail.p + 32);
+    if (int rc = ssa_verify_batch_msm_device(ctx, s.sigs, s.pks, s.msgs, s.off, msg_stride, msg_len, n,
+                                             (const u8 *)p, cb, d_verdict))
+        return rc;
+    uint32_t v = SSA_MALFORMED;
+    HIP_TRY(hipMemcpyAsync(&v, d_verdict, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return (int)v;
+}

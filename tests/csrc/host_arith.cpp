@@ -3,7 +3,7 @@
 // multiply-accumulate that has a C twin, so it can be unit-tested against the oracle on a
 // machine without a GPU.  The shipped library never executes this code on the CPU.
 //   hipcc --cuda-host-only -x hip -O2 -shared -fPIC host_arith.cpp -o libhost_arith.so
-#define SSA_HOST_TEST 1
+#define SSA_NO_KERNELS 1
 #include <cstring>
 #include "../../schnorr-sig_amd/csrc/ssa_kernels.cuh"
 

@@ -578,3 +578,95 @@ def test_decompress_many_vs_oracle(engine, oracle):
     assert ssa.PublicKey.from_bytes(fixtures[1], engine) is None
     rt = ssa.PublicKey.from_bytes(comp[5].tobytes(), engine)
     assert rt == ssa.PublicKey(pks[5].tobytes()) and rt.to_bytes() == comp[5].tobytes()
+
+
+# ---------------------------------------------------------------- MSM-form verify_batch
+def _batch(engine, rng, n, msg_len=80):
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, msg_len), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    coeffs = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    coeffs[:, 31] &= 0x3F
+    return sigs, pks, msgs, coeffs
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 300, 1024, 5000])
+def test_verify_batch_msm_vs_oracle(engine, oracle, n):
+    """The reference's own batch algorithm (src/batch.rs:56-130) on the GPU against its C restatement,
+    same coefficients: honest batch, swapped keys (src/batch.rs:177-178), one corrupted scalar."""
+    rng = np.random.default_rng(500 + n)
+    sigs, pks, msgs, coeffs = _batch(engine, rng, n)
+    assert engine.verify_batch_msm(sigs, pks, msgs, coeffs=coeffs) == 0
+    if n <= 1024:
+        assert oracle.verify_batch_msm(sigs, pks, msgs, coeffs) == 0
+    assert engine.verify_batch_msm(sigs, pks, msgs) == 0                  # library-drawn 128-bit coefficients
+    bad = sigs.copy()
+    bad[n // 2, 55] ^= 8
+    assert engine.verify_batch_msm(bad, pks, msgs, coeffs=coeffs) == 2
+    assert engine.verify_batch_msm(bad, pks, msgs) == 2
+    if n <= 300:
+        assert oracle.verify_batch_msm(bad, pks, msgs, coeffs) == 2
+    if n >= 3:
+        sw = pks.copy()
+        sw[[1, 2]] = sw[[2, 1]]
+        assert engine.verify_batch_msm(sigs, sw, msgs, coeffs=coeffs) == 2
+
+
+def test_verify_batch_msm_golden_batch5_and_repeated_keys(engine, oracle):
+    g = _gold()["batch5"]
+    sigs = np.frombuffer(bytes.fromhex("".join(g["sigs"])), dtype=np.uint8).reshape(5, 81)
+    pks = np.frombuffer(bytes.fromhex("".join(g["pks"])), dtype=np.uint8).reshape(5, 96)
+    coeffs = np.frombuffer(bytes.fromhex("".join(g["coeffs"])), dtype=np.uint8).reshape(5, 32)
+    msgs = [bytes.fromhex(x) for x in g["msgs"]]
+    flat = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8)
+    off = np.cumsum([0] + [len(x) for x in msgs]).astype(np.uint64)
+    assert engine.verify_batch_msm(sigs, pks, flat, offsets=off, coeffs=coeffs) == g["status"] == 0
+    sw = pks.copy()
+    sw[[1, 2]] = sw[[2, 1]]
+    assert engine.verify_batch_msm(sigs, sw, flat, offsets=off, coeffs=coeffs) == g["status_swapped_1_2"] == 2
+    # many signatures under ONE key and equal coefficients: equal points meet in one bucket (doubling inside jac_madd)
+    rng = np.random.default_rng(77)
+    n = 256
+    sk = make_scalars(rng, 1).repeat(n, axis=0)
+    nonces = make_scalars(rng, n)
+    m2 = rng.integers(0, 256, size=(n, 12), dtype=np.uint8)
+    pk2, sg2 = engine.keygen_sign_many(sk, nonces, m2)
+    c2 = np.tile(make_scalars(rng, 1), (n, 1))
+    assert engine.verify_batch_msm(sg2, pk2, m2, coeffs=c2) == oracle.verify_batch_msm(sg2, pk2, m2, c2) == 0
+    sg2[9, 49] ^= 1
+    assert engine.verify_batch_msm(sg2, pk2, m2, coeffs=c2) == oracle.verify_batch_msm(sg2, pk2, m2, c2) == 2
+
+
+def test_verify_batch_msm_divergence_classes(engine, oracle):
+    """Where the MSM form differs from n x Signature::verify (DESIGN.md): the flag byte of sig.x matters
+    (class iii), an x off the curve panics in the reference (class ii -> SSA_MALFORMED), no torsion check."""
+    rng = np.random.default_rng(88)
+    sigs, pks, msgs, coeffs = _batch(engine, rng, 40, 24)
+    flipped = sigs.copy()
+    flipped[7, 48] ^= 0x40                                   # R -> -R: per-lane verify is x-only and still accepts
+    st, _ = engine.verify_many(flipped, pks, msgs, check_torsion=True)
+    assert (st == 0).all()
+    assert engine.verify_batch_msm(flipped, pks, msgs, coeffs=coeffs) == 2
+    assert oracle.verify_batch_msm(flipped, pks, msgs, coeffs) == 2
+    off = sigs.copy()
+    off[3, :8] = np.frombuffer((12345).to_bytes(8, "little"), dtype=np.uint8)   # canonical x, (almost surely) no point
+    want = oracle.verify_batch_msm(off, pks, msgs, coeffs)
+    got = engine.verify_batch_msm(off, pks, msgs, coeffs=coeffs)
+    assert got == want and got in (2, 3)
+    bad = sigs.copy()
+    bad[5, 0:8] = 0xFF                                        # non-canonical limb: unwrap panics (src/batch.rs:67)
+    assert engine.verify_batch_msm(bad, pks, msgs, coeffs=coeffs) == 3
+    assert engine.verify_batch_msm(np.zeros((0, 81), np.uint8), np.zeros((0, 96), np.uint8),
+                                   np.zeros((0, 4), np.uint8)) == 0
+
+
+def test_verify_batch_msm_full_size(engine):
+    """2^20 signatures through the MSM form: honest batch accepts, a single corrupted signature rejects."""
+    rng = np.random.default_rng(0x5C4E0222)
+    n = 1 << 20
+    sigs, pks, msgs, coeffs = _batch(engine, rng, n)
+    assert engine.verify_batch_msm(sigs, pks, msgs, coeffs=coeffs) == 0
+    assert engine.verify_batch_msm(sigs, pks, msgs) == 0
+    sigs[123456, 60] ^= 1
+    assert engine.verify_batch_msm(sigs, pks, msgs, coeffs=coeffs) == 2
+    assert engine.verify_batch_msm(sigs, pks, msgs) == 2
