@@ -12,9 +12,11 @@
 //                      indices of each bucket; msm_k_bounds finds the bucket extents
 //   3. msm_k_buckets   ONE BUCKET PER LANE: a lane adds up the points of its bucket with mixed
 //                      additions (every exceptional case handled: equal public keys land in one bucket)
-//   4. msm_k_chunks    running-sum trick on chunks of 64 buckets; msm_k_windows sums the chunks of a
-//                      window and shifts it by 2^(c j); msm_k_finish adds the windows, computes
-//                      [lin]G from the comb table and compares the x coordinates
+//   4. msm_k_chunks    running-sum trick on chunks of 8 buckets (short chains, 2^17 lanes);
+//                      msm_k_tree (x5) sums the chunk sums of a window; msm_k_shift multiplies window j
+//                      by 2^(c j) with ONE WAVE PER POINT (wave-cooperative Fp6 arithmetic: the only long
+//                      sequential chain of the method); msm_k_finish adds the windows, computes [lin]G
+//                      from the comb table and compares the x coordinates
 // Panics of the reference (undecodable x, x not on the curve: src/batch.rs:67,104) give SSA_MALFORMED.
 #define SSA_NO_KERNELS 1
 #include "ssa_ctx.hpp"
@@ -25,7 +27,8 @@
 
 namespace ssa {
 
-constexpr int MSM_CHUNK = 64;  // buckets per lane in the running-sum pass
+constexpr int MSM_CHUNK = 8;   // buckets per lane in the running-sum pass (short chains, many lanes)
+constexpr u32 MSM_TREE_GROUP = 8;
 
 struct MsmShape {
     u32 c;        // window bits
@@ -191,17 +194,114 @@ msm_k_chunks(const u64 *__restrict__ bsum, MsmShape sh, u64 *__restrict__ chunk_
     st_jac(chunk_out + 18 * t, total);
 }
 
-// window j: W_j = sum of its chunks, shifted by 2^(c j)
+// tree step: out[j][g] = sum of `group` consecutive points of window j's `count` inputs
 __global__ void __launch_bounds__(64, 2)
-msm_k_windows(const u64 *__restrict__ chunk_in, MsmShape sh, u64 *__restrict__ win_out) {
-    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= sh.windows) return;
+msm_k_tree(const u64 *__restrict__ in, u32 windows, u32 count, u32 group, u64 *__restrict__ out) {
+    const u32 groups = (count + group - 1) / group;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= windows * groups) return;
+    const u32 j = t / groups, g = t % groups;
+    const u32 lo = g * group, hi = (lo + group < count) ? lo + group : count;
     jac acc = jac_identity();
 #pragma unroll 1
-    for (u32 ch = 0; ch < sh.chunks; ch++) acc = jac_add(acc, ld_jac(chunk_in + 18 * ((size_t)j * sh.chunks + ch)));
+    for (u32 k = lo; k < hi; k++) acc = jac_add(acc, ld_jac(in + 18 * ((size_t)j * count + k)));
+    st_jac(out + 18 * (size_t)t, acc);
+}
+
+// ---- wave-cooperative Fp6 arithmetic for the one sequential chain of the reduction ---------------
+// Shifting window j by 2^(c j) is a chain of up to 240 dependent doublings.  A lone lane runs it at a
+// few percent of a SIMD's issue rate (measured: ~80 us per doubling), so one WAVE works on one point
+// instead: the 36 products of an Fp6 multiplication go to 36 lanes, six lanes add up the columns and
+// reduce; operands live in LDS.  Only doubling is needed here.
+struct CoopLds {
+    u64 slot[16][6];      // Fp6 values
+    u64 part[6][6][2];    // 128-bit products grouped by output coefficient
+    u64 b7[6];            // 7 * b_j for the wrapped terms
+};
+
+__device__ __forceinline__ void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane) {
+    if (lane < 6) L.b7[lane] = fp_mul_small(L.slot[b][lane], 7u);
+    __syncthreads();
+    if (lane < 36) {
+        const u32 i = lane / 6, j = lane % 6;
+        u32 k = i + j;
+        u64 bb = L.slot[b][j];
+        if (k >= 6) {
+            k -= 6;
+            bb = L.b7[j];
+        }
+        u64 lo, hi;
+        mul64x64(L.slot[a][i], bb, lo, hi);
+        L.part[k][i][0] = lo;
+        L.part[k][i][1] = hi;
+    }
+    __syncthreads();
+    if (lane < 6) {
+        u64 lo = 0, hi = 0, top = 0;
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const u64 plo = L.part[lane][t][0], phi = L.part[lane][t][1];
+            const u64 nlo = lo + plo;
+            const u64 c0 = nlo < plo;
+            const u64 nh1 = hi + phi;
+            const u64 c1 = nh1 < phi;
+            const u64 nh2 = nh1 + c0;
+            const u64 c2 = nh2 < c0;
+            lo = nlo;
+            hi = nh2;
+            top += c1 + c2;
+        }
+        L.slot[dst][lane] = fp_reduce_parts(lo, lo32(hi), (u64)hi32(hi) + (top << 32));
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void coop_add(CoopLds &L, int dst, int a, int b, u32 lane) {
+    if (lane < 6) L.slot[dst][lane] = fp_add(L.slot[a][lane], L.slot[b][lane]);
+    __syncthreads();
+}
+__device__ __forceinline__ void coop_sub(CoopLds &L, int dst, int a, int b, u32 lane) {
+    if (lane < 6) L.slot[dst][lane] = fp_sub(L.slot[a][lane], L.slot[b][lane]);
+    __syncthreads();
+}
+
+// window j (one wave per window): W_j <- [2^(c j)] W_j with cooperative dbl-2007-bl doublings
+__global__ void __launch_bounds__(64)
+msm_k_shift(const u64 *__restrict__ win_in, MsmShape sh, u64 *__restrict__ win_out) {
+    __shared__ CoopLds L;
+    const u32 j = blockIdx.x, lane = threadIdx.x;
+    enum { X = 0, Y, Z, XX, YY, YYYY, ZZ, T, S, M, U, V };
+    if (lane < 18) L.slot[lane / 6][lane % 6] = win_in[18 * (size_t)j + lane];
+    __syncthreads();
 #pragma unroll 1
-    for (u32 s = 0; s < j * sh.c; s++) acc = jac_dbl(acc);
-    st_jac(win_out + 18 * (size_t)j, acc);
+    for (u32 s = 0; s < j * sh.c; s++) {
+        coop_mul(L, XX, X, X, lane);
+        coop_mul(L, YY, Y, Y, lane);
+        coop_mul(L, YYYY, YY, YY, lane);
+        coop_mul(L, ZZ, Z, Z, lane);
+        coop_add(L, T, X, YY, lane);
+        coop_mul(L, T, T, T, lane);
+        coop_sub(L, T, T, XX, lane);
+        coop_sub(L, T, T, YYYY, lane);
+        coop_add(L, S, T, T, lane);            // S = 2((X+YY)^2 - XX - YYYY)
+        coop_add(L, M, XX, XX, lane);
+        coop_add(L, M, M, XX, lane);
+        coop_mul(L, U, ZZ, ZZ, lane);
+        coop_add(L, M, M, U, lane);            // M = 3XX + ZZ^2  (a = 1)
+        coop_add(L, U, Y, Z, lane);            // (Y + Z) before X, Y, Z are overwritten
+        coop_mul(L, U, U, U, lane);
+        coop_sub(L, U, U, YY, lane);
+        coop_sub(L, Z, U, ZZ, lane);           // Z3 = (Y+Z)^2 - YY - ZZ
+        coop_mul(L, V, M, M, lane);
+        coop_sub(L, V, V, S, lane);
+        coop_sub(L, X, V, S, lane);            // X3 = M^2 - 2S
+        coop_sub(L, V, S, X, lane);
+        coop_mul(L, V, M, V, lane);
+        coop_add(L, U, YYYY, YYYY, lane);
+        coop_add(L, U, U, U, lane);
+        coop_add(L, U, U, U, lane);            // 8 YYYY
+        coop_sub(L, Y, V, U, lane);            // Y3 = M (S - X3) - 8 YYYY
+    }
+    if (lane < 18) win_out[18 * (size_t)j + lane] = L.slot[lane / 6][lane % 6];
 }
 
 // left = sum_j W_j ; right = [lin] G ; verdict: x-only comparison (src/batch.rs:125-129)
@@ -284,7 +384,8 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
         ctx->msm_keys.reserve(total * 4) || ctx->msm_vals.reserve(total * 4) || ctx->msm_keys2.reserve(total * 4) ||
         ctx->msm_vals2.reserve(total * 4) || ctx->msm_sort_tmp.reserve(sort_tmp + 16) ||
         ctx->msm_bounds.reserve(nb * 8) || ctx->msm_buckets.reserve(nb * 144) ||
-        ctx->msm_chunks.reserve((size_t)sh.windows * sh.chunks * 144) || ctx->msm_windows.reserve(sh.windows * 144) ||
+        ctx->msm_chunks.reserve((size_t)sh.windows * sh.chunks * 144) ||
+        ctx->msm_windows.reserve((size_t)sh.windows * sh.chunks * 144) ||
         ctx->msm_partials.reserve((size_t)n_blocks * 32) || ctx->msm_flags.reserve(64))
         return SSA_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
@@ -314,11 +415,23 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
     });
     if (rc) return rc;
     return timed_launch(ctx, "msm_reduce", [&] {
+        // per window: running sums on chunks of MSM_CHUNK buckets, a tree over the chunk sums, the
+        // 2^(c j) shift by one cooperating wave per window, then the final sum and comparison
         hipLaunchKernelGGL(msm_k_chunks, dim3(grid_for((size_t)sh.windows * sh.chunks, 256)), dim3(256), 0,
                            ctx->stream, (const u64 *)ctx->msm_buckets.p, sh, (u64 *)ctx->msm_chunks.p);
-        hipLaunchKernelGGL(msm_k_windows, dim3(grid_for(sh.windows, 64)), dim3(64), 0, ctx->stream,
-                           (const u64 *)ctx->msm_chunks.p, sh, (u64 *)ctx->msm_windows.p);
-        hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)ctx->msm_windows.p, sh,
+        u64 *ping = (u64 *)ctx->msm_chunks.p, *pong = (u64 *)ctx->msm_windows.p;
+        u32 count = sh.chunks;
+        while (count > 1) {
+            const u32 groups = (count + MSM_TREE_GROUP - 1) / MSM_TREE_GROUP;
+            hipLaunchKernelGGL(msm_k_tree, dim3(grid_for((size_t)sh.windows * groups, 64)), dim3(64), 0, ctx->stream,
+                               (const u64 *)ping, sh.windows, count, MSM_TREE_GROUP, pong);
+            u64 *tmp = ping;
+            ping = pong;
+            pong = tmp;
+            count = groups;
+        }
+        hipLaunchKernelGGL(msm_k_shift, dim3(sh.windows), dim3(64), 0, ctx->stream, (const u64 *)ping, sh, pong);
+        hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)pong, sh,
                            (const u64 *)ctx->msm_partials.p, n_blocks, (const u64 *)ctx->d_gtab,
                            (const u32 *)ctx->msm_flags.p, d_verdict_out);
     });
