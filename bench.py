@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--skip-torsion-leg", action="store_true", help="profiling runs: only the timed steps")
+    ap.add_argument("--distribute", action="store_true",
+                    help="N>1: generate the whole batch on rank 0 and scatter the shards over RCCL (timed "
+                         "separately as scatter_ms) instead of generating each shard in place")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,6 +89,23 @@ def main():
     eng.keygen_sign_many_device(sks.data_ptr(), nonces.data_ptr(), msgs.data_ptr(), n, 80, pks.data_ptr(),
                                 sigs.data_ptr())
     eng.sync()
+    scatter_ms = None
+    if args.distribute and dist is not None:
+        # rank 0 holds the whole world*n batch (its own shard repeated is enough to exercise the path:
+        # what matters is bytes moved); every rank receives its shard by direct scatter
+        from schnorr_sig_amd.sharding import scatter_rows
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = time.perf_counter()
+        full = {}
+        for name, t_, w in (("sigs", sigs, 81), ("pks", pks, 96), ("msgs", msgs, 80)):
+            full[name] = t_.repeat(world, 1) if rank == 0 else None
+            got = scatter_rows(full[name], world * n, w, rank, world, dist, device=dev)
+            t_.copy_(got)
+        torch.cuda.synchronize()
+        dist.barrier()
+        scatter_ms = (time.perf_counter() - ts) * 1e3
+        del full
     n_bad_expected = 0
     if args.corrupt > 0:
         n_bad_expected = int(n * args.corrupt)
@@ -199,6 +219,7 @@ def main():
             "with_torsion_check_rejected": total_fail_t,
             "kernels_ms": {"ssa_k_verify": k_verify_ms, "ssa_k_hash": k_hash_ms, "launches": k_cnt},
             "verify_batch_msm_form": msm,
+            "scatter_ms": scatter_ms,
             "roofline": {
                 "bound": "valu-int64 (not hbm, not mfma: SURVEY.md 8(d))",
                 "kernel": "ssa_k_verify",
@@ -225,7 +246,7 @@ def main():
         except Exception as exc:  # pragma: no cover
             out["measured_fpmul_peak"] = str(exc)
 
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as orc_mod
             try:

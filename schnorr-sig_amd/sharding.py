@@ -43,3 +43,27 @@ def gather_status(local_status_tensor, n, rank, world, dist):
         lo, hi = shard_range(n, r, world)
         out.append(parts[r][: hi - lo])
     return torch.cat(out)
+
+
+def scatter_rows(full, n, row_bytes, rank, world, dist, device=None, src=0):
+    """Input distribution for a batch that is resident on rank `src`: every rank receives its own
+    contiguous shard of the (n, row_bytes) uint8 array, each shard crossing one link once (direct
+    scatter; a broadcast of the whole array would move `world` times the bytes and is ring/per-link
+    bound on xGMI).  `full` is only read on rank `src`.  Ragged shards are padded to the largest."""
+    import torch
+    lo, hi = shard_range(n, rank, world)
+    if dist is None or world == 1:
+        return full[lo:hi]
+    width = (n + world - 1) // world
+    dev = device if device is not None else (full.device if full is not None else "cpu")
+    out = torch.empty((width, row_bytes), dtype=torch.uint8, device=dev)
+    chunks = None
+    if rank == src:
+        chunks = []
+        for r in range(world):
+            a, b = shard_range(n, r, world)
+            c = torch.zeros((width, row_bytes), dtype=torch.uint8, device=dev)
+            c[: b - a] = full[a:b]
+            chunks.append(c)
+    dist.scatter(out, chunks, src=src)
+    return out[: hi - lo]

@@ -21,13 +21,17 @@ def _worker(rank, world, port, n, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import Oracle
-    from schnorr_sig_amd.sharding import aggregate_fail_count, batch_verdict, gather_status, shard_range
+    from schnorr_sig_amd.sharding import aggregate_fail_count, batch_verdict, gather_status, scatter_rows, shard_range
     orc = Oracle()
     rng = np.random.default_rng(77)     # every rank derives the same global batch
     sks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); sks[:, 31] &= 0x3F; sks[:, 0] |= 1
     nonces = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); nonces[:, 31] &= 0x3F; nonces[:, 0] |= 1
     msgs = rng.integers(0, 256, size=(n, 80), dtype=np.uint8)
     lo, hi = shard_range(n, rank, world)
+    # rank-0-resident messages reach the other ranks by scatter; must equal the local slice
+    full = torch.from_numpy(msgs) if rank == 0 else None
+    got = scatter_rows(full, n, 80, rank, world, dist)
+    assert (got.numpy() == msgs[lo:hi]).all()
     pks, sigs = orc.keygen_sign_many(sks[lo:hi], nonces[lo:hi], msgs[lo:hi], threads=2)
     bad_global = [3, n // 2, n - 1]
     for b in bad_global:
