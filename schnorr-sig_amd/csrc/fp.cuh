@@ -30,13 +30,6 @@ SSA_DEV u32 lo32(u64 x) { return (u32)x; }
 SSA_DEV u32 hi32(u64 x) { return (u32)(x >> 32); }
 SSA_DEV u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
-// (carry, sum) helpers: the compiler maps these to v_add_co/v_addc_co chains.
-SSA_DEV u64 add_c(u64 a, u64 b, u32 &carry) {
-    u64 s = a + b;
-    carry = s < a;
-    return s;
-}
-
 // a + b (mod p), loose in / loose out.  A carry out of 2^64 is worth EPS; the corrected
 // sum can wrap once more only when it is then < EPS, so the second fix touches the low
 // word alone.
