@@ -31,8 +31,10 @@ SSA_DEV u32 hi32(u64 x) { return (u32)(x >> 32); }
 SSA_DEV u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
 // a + b (mod p), loose in / loose out.  A carry out of 2^64 is worth EPS; the corrected
-// sum can wrap once more only when it is then < EPS, so the second fix touches the low
-// word alone.
+// sum can wrap once more only when both inputs are above p.
+// (Measured: hand-written v_add_co/v_addc_co/v_subb VCC carry chains for fp_add, fp_sub and the
+// reductions have fewer instructions than what hipcc emits from this C++ -- v_lshl_add_u64 +
+// v_cmp_lt_u64 + v_cndmask -- but ran 7-16 % slower: dependent VCC hops serialise.)
 SSA_DEV u64 fp_add(u64 a, u64 b) {
     u64 s = a + b;
     u32 c = s < a;
