@@ -120,6 +120,9 @@ SSA_DEV void acc_zero(fp_acc &s) {
 }
 
 // s += a*b.  One asm block per 64x64 product: four v_mad_u64_u32 whose carry-outs feed
+// (measured on MI355X, lazy Fp6 probe: this block 2.82e12 products/s; the four mads issued first and
+// the carry adds last 2.82e12; plain C++ carry detection 1.77e12; NO carry tracking -- wrong results,
+// upper bound -- 3.78e12: the carries are the price of 64-bit columns)
 // v_addc_co_u32 on the column counters; the independent mads are placed between each
 // carry's producer and consumer, and two scratch SGPR pairs keep three carries in flight.
 SSA_DEV void acc_mac(fp_acc &s, u64 a, u64 b) {
