@@ -196,8 +196,14 @@ def main():
                     traffic = json.load(fh)["ssa_k_verify"]["hbm_bytes_per_launch"]
         except Exception:
             pass
+        metric = "Schnorr verifications/sec, 2^20-sig batch, 1/2/4/8 MI355X; bit-exact vs CPU"
+        try:
+            with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+                metric = json.load(fh)["metric"]
+        except Exception:
+            pass
         out = {
-            "metric": "schnorr_verifications_per_sec",
+            "metric": metric,
             "value": value,
             "unit": "verifications/s",
             "n_gpus": world,
@@ -221,7 +227,9 @@ def main():
             "verify_batch_msm_form": msm,
             "scatter_ms": scatter_ms,
             "roofline": {
-                "bound": "valu-int64 (not hbm, not mfma: SURVEY.md 8(d))",
+                "bound": "valu",
+                "bound_note": "64-bit integer VALU (v_mad_u64_u32), neither hbm nor mfma: SURVEY.md 8(d); peak = "
+                              "256 CU x 4 SIMD x 32 lanes x 2.4 GHz / 16 lane-slots per 64x64 product",
                 "kernel": "ssa_k_verify",
                 "achieved": achieved / 1e9,
                 "peak": PEAK_FPMUL / 1e9,
