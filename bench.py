@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20, help="signatures per GPU per step")
+    ap.add_argument("--batch", dest="n", type=int, default=1 << 20, help="signatures per GPU per step")
     ap.add_argument("--corrupt", type=float, default=0.0, help="fraction of corrupted signatures (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
@@ -63,15 +63,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # SSA_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks share a
+    # device; RCCL refuses that).  The driver's runs use the default: nccl == RCCL, one GPU per rank.
+    backend = os.environ.get("SSA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     n = args.n
 
-    eng = ssa.Engine(local_rank)
-    stream = torch.cuda.current_stream()
+    eng = ssa.Engine(dev_index)
+    # one explicit stream for everything: the engine's kernels, torch's fills and the collectives.
+    # (torch's default stream has handle 0, which the C ABI reads as "use the context's own stream".)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
 
     # ---- synthetic inputs, generated on the device (seed per rank) ----
@@ -122,7 +132,12 @@ def main():
         eng.verify_many_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, status.data_ptr(),
                                nfail.data_ptr(), check_torsion=check_torsion)
         if dist is not None:
-            dist.all_reduce(nfail)       # aggregate verdict of the sharded batch
+            if backend == "nccl":
+                dist.all_reduce(nfail)   # aggregate verdict of the sharded batch (RCCL, 8 bytes)
+            else:                        # rehearsal backend: reduce through the host
+                host = nfail.cpu()
+                dist.all_reduce(host)
+                nfail.copy_(host)
 
     def sync_all():
         if dist is not None:
@@ -143,10 +158,13 @@ def main():
     k_verify_ms, k_cnt = eng.read_timing("ssa_k_verify")
     k_hash_ms, _ = eng.read_timing("ssa_k_hash")
     total_fail = int(nfail.item())
+    if os.environ.get("SSA_BENCH_DEBUG"):
+        print("[rank %d] total_fail after all-reduce = %d, local status!=0 = %d" %
+              (rank, total_fail, int((status != 0).sum().item())), file=sys.stderr)
     ok = (total_fail == n_bad_expected * world) if args.corrupt > 0 else (total_fail == 0)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

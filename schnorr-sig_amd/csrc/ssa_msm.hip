@@ -342,15 +342,12 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
 
 // ------------------------------------------------------------------------------------------------
 static MsmShape msm_shape(size_t n) {
-    // mean bucket occupancy 2n / 2^c of about 32 keeps the one-bucket-per-lane pass balanced
-    size_t pts = 2 * n;
-    u32 lg = 0;
-    while ((1ull << (lg + 1)) <= pts) lg++;
-    int c = (int)lg - 5;
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
+    // Window width: 16 bits, or 8 for small batches.  Both divide 128 (library-drawn coefficients) and
+    // leave a wide top window for 255-bit scalars (255 mod 16 = 15, 255 mod 8 = 7): a narrow partial
+    // window would have a handful of digits and therefore a handful of enormous buckets (measured:
+    // c = 14 put n/4 points into single lanes and took 0.9 s at n = 2^18).
     MsmShape sh;
-    sh.c = (u32)c;
+    sh.c = n >= 4096 ? 16u : 8u;
     sh.windows = (255 + sh.c - 1) / sh.c;
     sh.buckets = 1u << sh.c;
     sh.chunks = sh.buckets <= (u32)MSM_CHUNK ? 1u : sh.buckets / (u32)MSM_CHUNK;
