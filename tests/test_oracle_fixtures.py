@@ -207,3 +207,15 @@ def test_config1_1024_signatures_through_cpu_verify_batch(oracle):
     assert oracle.verify_batch_msm(sigs, pks, msgs, coeffs) == 2
     st = oracle.verify_many(sigs, pks, msgs, check_torsion=False)
     assert st[517] == 2 and st.sum() == 2
+
+
+def test_mds_matrix_has_no_singular_minor(tmp_path):
+    """The recalled circulant is a valid Rescue MDS layer over Goldilocks: all 2 704 155 square
+    submatrices are non-singular (oracle/tools/mds_check.c, exhaustive)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "mds_check")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(root, "oracle", "tools", "mds_check.c")])
+    out = subprocess.run([exe, os.path.join(root, "schnorr-sig_amd", "params", "params_default.bin")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip() == "MDS ok 2704155", out.stdout
