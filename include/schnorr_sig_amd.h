@@ -118,7 +118,7 @@ int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, cons
  * comparison.  coeffs: n x 32-byte scalars standing in for Scalar::random(rng) (reduced mod q), or
  * NULL for 128-bit coefficients drawn from getrandom(2).  Returns SSA_OK, SSA_INVALID_SIGNATURE, or
  * SSA_MALFORMED where the reference panics (undecodable sig.x, src/batch.rs:67,104).  No torsion
- * check, like the reference. */
+ * check, like the reference.  n <= 2^25 per call. */
 int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
                          const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
                          const uint8_t *coeffs);

@@ -361,7 +361,7 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
     if (!ctx || !d_verdict_out) return SSA_ERR_ARG;
     if (n && (!d_sigs || !d_pks || !d_coeffs)) return SSA_ERR_ARG;
     if (coeff_bytes == 0 || coeff_bytes > 32) return SSA_ERR_ARG;
-    if (n > (1ull << 27)) return SSA_ERR_ARG;   // 32-bit sort positions
+    if (n > (1ull << 25)) return SSA_ERR_ARG;   // 2n * 16 sort items must fit hipCUB's int item count
     if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     if (n == 0) {   // empty batch: Ok (src/batch.rs)
