@@ -207,11 +207,12 @@ def main():
         value = world * n * args.steps / elapsed
         w_kernel = W_VERIFY_KERNEL
         achieved = w_kernel * n / (k_verify_ms * 1e-3) if k_verify_ms > 0 else 0.0
-        traffic = None   # HBM bytes per ssa_k_verify launch from the committed PMC passes (same workload)
+        traffic, valu_util = None, None   # from the committed PMC passes of the same workload (profiles/r01)
         try:
             with open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_v2.json")) as fh:
                 if n == 1 << 20:
-                    traffic = json.load(fh)["ssa_k_verify"]["hbm_bytes_per_launch"]
+                    pmc = json.load(fh)["ssa_k_verify"]
+                    traffic, valu_util = pmc["hbm_bytes_per_launch"], pmc["valu_issue_utilisation"]
         except Exception:
             pass
         metric = "Schnorr verifications/sec, 2^20-sig batch, 1/2/4/8 MI355X; bit-exact vs CPU"
@@ -256,6 +257,7 @@ def main():
                 "work_per_unit": w_kernel,
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01)",
+                "valu_issue_utilisation_pmc": valu_util,
             },
             "roofline_hbm": {
                 "bound": "hbm",
