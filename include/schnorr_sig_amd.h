@@ -15,6 +15,7 @@
  *                              BASELINE.json's north_star asks for)
  *   ssa_hash_message_many   <- hash_message                 src/signature.rs:274-306
  *   ssa_rescue_hash_many    <- RescueHash::hash_field       src/signature.rs:303
+ *   ssa_verify_keyed_many   <- KeyedSignature::{from_bytes, verify}  src/signature.rs:232-271
  *   ssa_decompress_many     <- PublicKey::from_bytes / AffinePoint::from_compressed
  *                                                           src/public.rs:54-56, src/batch.rs:104
  *   ssa_keygen_sign_many    <- KeyPair::new / KeyPair::sign src/keypair.rs:57-65,
@@ -138,6 +139,14 @@ int ssa_rescue_hash_many(ssa_ctx *ctx, const uint64_t *felts, uint32_t felts_per
 int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces,
                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
                          size_t msg_len, size_t n, uint8_t *pks_out, uint8_t *sigs_out);
+
+#define SSA_KEYED_SIGNATURE_LENGTH 130  /* src/constants.rs:30 */
+/* n x KeyedSignature::verify on the 130-byte wire form pk(49, compressed) || sig(81)
+ * (src/signature.rs:232-271): the key is decompressed on the GPU, then verified as ssa_verify_many.
+ * A record whose key or scalar does not decode (KeyedSignature::from_bytes is_none) gets SSA_MALFORMED. */
+int ssa_verify_keyed_many(ssa_ctx *ctx, const uint8_t *keyed, const uint8_t *msgs, const uint64_t *msg_off,
+                          size_t msg_stride, size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,
+                          uint64_t *n_fail_out);
 
 /* PublicKey::from_bytes (src/public.rs:54-56): n x 49-byte compressed points (48 bytes of x, flag
  * byte: bit 7 = infinity, bit 6 = sort flag, other bits clear) -> n x 96-byte affine points.

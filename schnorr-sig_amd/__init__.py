@@ -87,6 +87,7 @@ def _load():
         "ssa_keygen_sign_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, vp]),
         "ssa_verify_batch_msm": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
         "ssa_verify_batch_msm_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, u32, vp]),
+        "ssa_verify_keyed_many": (i32, [vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
         "ssa_decompress_many": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_decompress_many_device": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_debug_arith": (i32, [vp, i32, vp, vp, sz, sz, sz, vp, sz]),
@@ -238,6 +239,18 @@ class Engine:
         _check(_lib.ssa_keygen_sign_many(self._ctx, _ptr(sks), _ptr(nonces), _ptr(m), _ptr(off), stride, mlen, n,
                                          _ptr(pks), _ptr(sigs)), "ssa_keygen_sign_many")
         return pks, sigs
+
+    def verify_keyed_many(self, keyed, msgs, offsets=None, check_torsion=True):
+        """n x KeyedSignature::verify on 130-byte records pk(49) || sig(81) -> (status, n_fail)."""
+        kd = _np_u8(keyed, 130)
+        n = kd.shape[0]
+        m, off, stride, mlen = self._msg_args(msgs, offsets, n)
+        status = np.full(n, 255, dtype=np.uint8)
+        nfail = C.c_uint64(0)
+        _check(_lib.ssa_verify_keyed_many(self._ctx, _ptr(kd), _ptr(m), _ptr(off), stride, mlen, n,
+                                          FLAG_CHECK_TORSION if check_torsion else 0, _ptr(status),
+                                          C.byref(nfail)), "ssa_verify_keyed_many")
+        return status, int(nfail.value)
 
     def decompress_many(self, compressed):
         """n x 49-byte compressed points -> (pks uint8[n,96], is_identity uint8[n], status uint8[n])."""
@@ -415,6 +428,31 @@ class Signature:
         return isinstance(o, Signature) and o.bytes == self.bytes
 
 
+class KeyedSignature:
+    """KeyedSignature{public_key, signature} (src/signature.rs:55-60); wire form pk(49) || sig(81)."""
+
+    def __init__(self, public_key, signature):
+        self.public_key = public_key
+        self.signature = signature
+
+    def to_bytes(self):  # src/signature.rs:236-243
+        return self.public_key.to_bytes() + self.signature.to_bytes()
+
+    @classmethod
+    def from_bytes(cls, b130, engine=None):  # src/signature.rs:246-271: None unless both halves decode
+        b = bytes(b130)
+        if len(b) != KEYED_SIGNATURE_LENGTH:
+            raise ValueError("KeyedSignature needs 130 bytes")
+        pk = PublicKey.from_bytes(b[:49], engine)
+        sig = Signature.from_bytes(b[49:])
+        if pk is None or sig is None:
+            return None
+        return cls(pk, sig)
+
+    def verify(self, message, engine=None):  # src/signature.rs:232-234
+        return self.signature.verify(message, self.public_key, engine)
+
+
 class KeyPair:
     """KeyPair{private_key, public_key} (src/keypair.rs:48-53)."""
 
@@ -444,6 +482,9 @@ class KeyPair:
 
     def verify_signature(self, signature, message):  # src/signature.rs:159-165
         return signature.verify(message, self.public_key)
+
+    def sign_and_bind_pkey(self, message, rng, engine=None):  # src/signature.rs:132-156
+        return KeyedSignature(self.public_key, self.sign(message, rng, engine))
 
 
 def verify_batch(signatures, public_keys, messages, rng=None, engine=None, msm=False):

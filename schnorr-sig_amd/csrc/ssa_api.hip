@@ -399,6 +399,37 @@ extern "C" int ssa_decompress_many(ssa_ctx *ctx, const uint8_t *compressed, size
     return 0;
 }
 
+extern "C" int ssa_verify_keyed_many(ssa_ctx *ctx, const uint8_t *keyed, const uint8_t *msgs,
+                                     const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                                     uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out) {
+    if (!ctx || (n && (!keyed || !status_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (n_fail_out) *n_fail_out = 0;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    StagedInputs s;
+    const void *p;
+    if (int rc = stage_up(ctx, ctx->st_coeffs, keyed, n * 130, &p)) return rc;
+    if (ctx->st_sigs.reserve(n * 81) || ctx->st_pks.reserve(n * 96) || ctx->st_inf.reserve(n + 16) ||
+        ctx->st_status.reserve(n + 16))
+        return SSA_ERR_HIP;
+    hipLaunchKernelGGL(ssa_k_unpack_keyed, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const u8 *)p, n,
+                       (u8 *)ctx->st_pks.p, (u8 *)ctx->st_inf.p, (u8 *)ctx->st_sigs.p);
+    HIP_TRY(hipGetLastError());
+    if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
+    unsigned long long *d_fail = (unsigned long long *)ctx->ws_fail.p;
+    if (int rc = ssa_verify_many_device(ctx, (const u8 *)ctx->st_sigs.p, (const u8 *)ctx->st_pks.p,
+                                        (const u8 *)ctx->st_inf.p, s.msgs, s.off, msg_stride, msg_len, n, flags,
+                                        (u8 *)ctx->st_status.p, (uint64_t *)d_fail))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(status_out, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long nf = 0;
+    HIP_TRY(hipMemcpyAsync(&nf, d_fail, sizeof nf, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_fail_out) *n_fail_out = nf;
+    return 0;
+}
+
 // ------------------------------------------------------------------ probes
 extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                                size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {

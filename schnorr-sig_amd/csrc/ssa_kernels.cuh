@@ -553,6 +553,27 @@ ssa_k_decompress(const u8 *__restrict__ comp, size_t n, u8 *__restrict__ pks_out
 }
 #endif  // SSA_NO_KERNELS
 
+// KeyedSignature wire form (src/signature.rs:236-271): pk (49 B compressed) || signature (81 B).
+// Splits n records into the affine keys / signatures the verification kernels consume; a key that
+// does not decompress becomes (0, 0), which ssa_k_verify reports as SSA_MALFORMED
+// (KeyedSignature::from_bytes is_none).
+#ifndef SSA_NO_KERNELS
+__global__ void __launch_bounds__(256)
+ssa_k_unpack_keyed(const u8 *__restrict__ keyed, size_t n, u8 *__restrict__ pks_out, u8 *__restrict__ inf_out,
+                   u8 *__restrict__ sigs_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u8 *rec = keyed + 130 * i;
+    aff p;
+    bool inf;
+    (void)decompress_lane(rec, p, inf);
+    st_fp6(pks_out + 96 * i, p.x);
+    st_fp6(pks_out + 96 * i + 48, p.y);
+    inf_out[i] = inf ? 1 : 0;
+    for (int k = 0; k < 81; k++) sigs_out[81 * i + k] = rec[49 + k];
+}
+#endif  // SSA_NO_KERNELS
+
 // ------------------------------------------------------------------------------------------
 // arithmetic probes (ssa_debug_arith)
 #ifndef SSA_NO_KERNELS

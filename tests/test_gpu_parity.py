@@ -735,3 +735,48 @@ def test_config4_size_2pow22_single_gpu(engine):
     assert engine.verify_batch_msm(sigs, pks, msgs) == 2
     sigs[bad, 49] ^= 1
     assert engine.verify_batch_msm(sigs, pks, msgs) == 0
+
+
+def test_keyed_signatures_wire_form(engine, oracle):
+    """KeyedSignature (src/signature.rs:55-60, 232-271): 130-byte records pk(49) || sig(81) verified with
+    the key decompressed on the GPU; undecodable halves give SSA_MALFORMED; object mirror round trip."""
+    import os as _os
+    import schnorr_sig_amd as ssa
+    rng = np.random.default_rng(41)
+    n = 512
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, 40), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    keyed = np.zeros((n, 130), dtype=np.uint8)
+    for i in range(n):
+        keyed[i, :49] = np.frombuffer(oracle.compress(pks[i].tobytes()), dtype=np.uint8)
+    keyed[:, 49:] = sigs
+    st, nf = engine.verify_keyed_many(keyed, msgs)
+    assert nf == 0 and (st == 0).all()
+    bad = keyed.copy()
+    bad[3, 48] ^= 0x40          # other root: a different (valid) key -> InvalidSignature
+    bad[4, 48] = 0xFF           # flag byte 255: decompression failed
+    bad[5, 60] ^= 1             # sig.x changed
+    bad[6, 49 + 49 + 31] = 0x7F # e >= q
+    bad[7, :8] = 0xFF           # pk limb >= p
+    st, nf = engine.verify_keyed_many(bad, msgs)
+    assert list(st[3:8]) == [2, 3, 2, 3, 3] and nf == 5 and (np.delete(st, [3, 4, 5, 6, 7]) == 0).all()
+    # identity key || a signature made with sk = 0 semantics (e = r): accepted (src/signature.rs:462-481 layout)
+    idk = np.zeros((1, 130), dtype=np.uint8)
+    idk[0, 48] = 0x80
+    r = make_scalars(rng, 1)
+    rpk, _ = engine.keygen_sign_many(r, r, np.zeros((1, 1), np.uint8))
+    idk[0, 49:49 + 48] = rpk[0, :48]
+    idk[0, 49 + 49:] = r[0]
+    st, nf = engine.verify_keyed_many(idk, np.zeros((1, 3), np.uint8))
+    assert st[0] == 0 and nf == 0
+    # object mirror
+    rnd = lambda k: _os.urandom(k)
+    kp = ssa.KeyPair.new(rnd, engine)
+    ks = kp.sign_and_bind_pkey(b"bound message", rnd, engine)
+    raw = ks.to_bytes()
+    assert len(raw) == ssa.KEYED_SIGNATURE_LENGTH
+    back = ssa.KeyedSignature.from_bytes(raw, engine)
+    assert back is not None and back.public_key == kp.public_key and back.signature == ks.signature
+    assert back.verify(b"bound message", engine) is None
+    assert ssa.KeyedSignature.from_bytes(raw[:48] + b"\xff" + raw[49:], engine) is None
