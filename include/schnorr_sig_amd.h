@@ -180,6 +180,17 @@ int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8
                                 uint32_t *d_verdict_out);
 int ssa_ctx_sync(ssa_ctx *ctx);
 
+/* ---- several GPUs of one node from a single process --------------------------------------------
+ * The batch shards by signature (contiguous ranges, sizes differ by at most one) over the listed
+ * devices -- one context and one host thread per device, no collective: every verification reads
+ * only its own record (src/signature.rs:181-205).  Same semantics as ssa_verify_many. */
+typedef struct ssa_multi ssa_multi;
+int ssa_multi_create(ssa_multi **out, const int *devices, int n_devices, const void *params, size_t params_len);
+void ssa_multi_destroy(ssa_multi *m);
+int ssa_multi_verify_many(ssa_multi *m, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                          size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out);
+
 /* ---- arithmetic probes (unit parity with the oracle; not part of the reference API) --- */
 /* op: 0 = Fp6 mul, 1 = Fp6 sqr, 2 = Fp6 inv, 3 = point add (affine 12+12 -> 12 felts + inf),
  *     4 = scalar mul [k]P (k in a[0..4], P in b), 5 = Fp mul (a[0]*b[0]), 6 = Fp inv */

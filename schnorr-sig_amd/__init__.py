@@ -88,6 +88,9 @@ def _load():
         "ssa_verify_batch_msm": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
         "ssa_verify_batch_msm_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, u32, vp]),
         "ssa_verify_keyed_many": (i32, [vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
+        "ssa_multi_create": (i32, [C.POINTER(vp), C.POINTER(i32), i32, vp, sz]),
+        "ssa_multi_destroy": (None, [vp]),
+        "ssa_multi_verify_many": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
         "ssa_decompress_many": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_decompress_many_device": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_debug_arith": (i32, [vp, i32, vp, vp, sz, sz, sz, vp, sz]),
@@ -316,6 +319,43 @@ class Engine:
         v = C.c_double(0)
         _check(_lib.ssa_bench_fpmul(self._ctx, variant, C.byref(v)), "ssa_bench_fpmul")
         return v.value
+
+
+class MultiEngine:
+    """Several GPUs of one node from a single process (ssa_multi_*): contiguous shards, one context
+    and one host thread per device, no collective."""
+
+    def __init__(self, devices, params=None):
+        self._m = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        blob = (C.c_uint8 * len(params)).from_buffer_copy(bytes(params)) if params is not None else None
+        _check(_lib.ssa_multi_create(C.byref(self._m), devs, len(devices), blob, len(params) if params else 0),
+               "ssa_multi_create")
+
+    def close(self):
+        if self._m:
+            _lib.ssa_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def verify_many(self, sigs, pks, msgs, offsets=None, check_torsion=True, pk_inf=None):
+        sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
+        n = sigs.shape[0]
+        m = _np_u8(msgs)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64) if offsets is not None else None
+        stride = mlen = 0 if off is not None else m.shape[1]
+        inf = _np_u8(pk_inf) if pk_inf is not None else None
+        status = np.full(n, 255, dtype=np.uint8)
+        nfail = C.c_uint64(0)
+        _check(_lib.ssa_multi_verify_many(self._m, _ptr(sigs), _ptr(pks), _ptr(inf), _ptr(m), _ptr(off), stride, mlen,
+                                          n, FLAG_CHECK_TORSION if check_torsion else 0, _ptr(status),
+                                          C.byref(nfail)), "ssa_multi_verify_many")
+        return status, int(nfail.value)
 
 
 _default_engine = None

@@ -4,6 +4,8 @@
 #define SSA_KERNELS_DEFINE 1
 #include "ssa_ctx.hpp"
 
+#include <thread>
+
 static const unsigned char k_default_params[SSA_PARAMS_LENGTH] = {
 #include "../params/params_default.inc"
 };
@@ -427,6 +429,81 @@ extern "C" int ssa_verify_keyed_many(ssa_ctx *ctx, const uint8_t *keyed, const u
     HIP_TRY(hipMemcpyAsync(&nf, d_fail, sizeof nf, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (n_fail_out) *n_fail_out = nf;
+    return 0;
+}
+
+// ------------------------------------------------------------------ several GPUs from one process
+// The path shards by signature with no data-path exchange (each verification reads only its own
+// record), so a host caller that owns the whole batch needs no collective at all: contiguous shards,
+// one context and one host thread per device, rejection counts summed on the host.
+struct ssa_multi {
+    std::vector<ssa_ctx *> ctxs;
+};
+
+extern "C" int ssa_multi_create(ssa_multi **out, const int *devices, int n_devices, const void *params,
+                                size_t params_len) {
+    if (!out || !devices || n_devices <= 0) return SSA_ERR_ARG;
+    *out = nullptr;
+    ssa_multi *m = new ssa_multi();
+    for (int i = 0; i < n_devices; i++) {
+        ssa_ctx *c = nullptr;
+        int rc = ssa_ctx_create(&c, devices[i], params, params_len);
+        if (rc != 0) {
+            for (ssa_ctx *x : m->ctxs) ssa_ctx_destroy(x);
+            delete m;
+            return rc;
+        }
+        m->ctxs.push_back(c);
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" void ssa_multi_destroy(ssa_multi *m) {
+    if (!m) return;
+    for (ssa_ctx *c : m->ctxs) ssa_ctx_destroy(c);
+    delete m;
+}
+
+extern "C" int ssa_multi_verify_many(ssa_multi *m, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                     const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
+                                     size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,
+                                     uint64_t *n_fail_out) {
+    if (!m || m->ctxs.empty() || (n && (!sigs || !pks || !status_out))) return SSA_ERR_ARG;
+    if (n_fail_out) *n_fail_out = 0;
+    if (n == 0) return 0;
+    const size_t world = m->ctxs.size();
+    std::vector<int> rcs(world, 0);
+    std::vector<uint64_t> fails(world, 0);
+    std::vector<std::thread> threads;
+    const size_t base = n / world, rem = n % world;
+    for (size_t r = 0; r < world; r++) {
+        const size_t lo = r * base + (r < rem ? r : rem), cnt = base + (r < rem ? 1 : 0);
+        threads.emplace_back([&, r, lo, cnt] {
+            if (cnt == 0) return;
+            // shard-local message view: offsets are rebased by pointing at msgs + off[lo]
+            std::vector<uint64_t> off;
+            const uint8_t *mbase = msgs;
+            const uint64_t *offp = nullptr;
+            if (msg_off) {
+                off.resize(cnt + 1);
+                for (size_t k = 0; k <= cnt; k++) off[k] = msg_off[lo + k] - msg_off[lo];
+                mbase = msgs + msg_off[lo];
+                offp = off.data();
+            } else {
+                mbase = msgs ? msgs + lo * msg_stride : nullptr;
+            }
+            rcs[r] = ssa_verify_many(m->ctxs[r], sigs + 81 * lo, pks + 96 * lo, pk_inf ? pk_inf + lo : nullptr, mbase,
+                                     offp, msg_stride, msg_len, cnt, flags, status_out + lo, &fails[r]);
+        });
+    }
+    for (auto &t : threads) t.join();
+    uint64_t total = 0;
+    for (size_t r = 0; r < world; r++) {
+        if (rcs[r] != 0) return rcs[r];
+        total += fails[r];
+    }
+    if (n_fail_out) *n_fail_out = total;
     return 0;
 }
 

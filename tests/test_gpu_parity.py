@@ -780,3 +780,30 @@ def test_keyed_signatures_wire_form(engine, oracle):
     assert back is not None and back.public_key == kp.public_key and back.signature == ks.signature
     assert back.verify(b"bound message", engine) is None
     assert ssa.KeyedSignature.from_bytes(raw[:48] + b"\xff" + raw[49:], engine) is None
+
+
+def test_multi_device_sharding_single_process(engine):
+    """ssa_multi_*: the shard/thread/sum logic of the single-process multi-GPU entry point, exercised with
+    three contexts on device 0 (ragged shards, variable-length messages); must equal the one-context result."""
+    import schnorr_sig_amd as ssa
+    rng = np.random.default_rng(51)
+    n = 1000
+    lens = rng.integers(0, 60, size=n)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    flat = rng.integers(0, 256, size=int(off[-1]) + 1, dtype=np.uint8)
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, flat, offsets=off)
+    bad = [0, 333, 334, 667, 999]
+    sigs[bad, 50] ^= 1
+    want, nf_want = engine.verify_many(sigs, pks, flat, offsets=off, check_torsion=True)
+    multi = ssa.MultiEngine([0, 0, 0])
+    try:
+        st, nf = multi.verify_many(sigs, pks, flat, offsets=off, check_torsion=True)
+        assert (st == want).all() and nf == nf_want == 5
+        dense = rng.integers(0, 256, size=(n, 16), dtype=np.uint8)
+        pk2, sg2 = engine.keygen_sign_many(sks, nonces, dense)
+        st2, nf2 = multi.verify_many(sg2, pk2, dense, check_torsion=False)
+        assert nf2 == 0 and (st2 == 0).all()
+    finally:
+        multi.close()
