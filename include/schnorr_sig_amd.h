@@ -68,6 +68,8 @@ extern "C" {
 #define SSA_ERR_NO_DEVICE (-4)
 
 /* flags */
+#define SSA_FLAG_FORCE_LANE 2u    /* always the throughput kernels (one signature per lane) */
+#define SSA_FLAG_FORCE_COOP 4u    /* always the low-latency kernel (one wave per signature) */
 #define SSA_FLAG_CHECK_TORSION 1u /* Signature::verify semantics (src/signature.rs:182-184);
                                      off = verify_batch semantics (src/batch.rs has no check) */
 

@@ -34,6 +34,9 @@ KEYED_SIGNATURE_LENGTH = 130
 
 OK, INVALID_PUBLIC_KEY, INVALID_SIGNATURE, MALFORMED = 0, 1, 2, 3
 FLAG_CHECK_TORSION = 1
+FLAG_FORCE_LANE = 2   # throughput kernels (one signature per lane) whatever the batch size
+FLAG_FORCE_COOP = 4   # low-latency kernel (one wave per signature) whatever the batch size
+_MODE_FLAGS = {None: 0, "auto": 0, "lane": FLAG_FORCE_LANE, "coop": FLAG_FORCE_COOP}
 
 Q = 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
 
@@ -170,8 +173,9 @@ class Engine:
         assert m.ndim == 2 and m.shape[0] == n, "dense messages must be an (n, len) array"
         return m, None, m.shape[1], m.shape[1]
 
-    def verify_many(self, sigs, pks, msgs, offsets=None, check_torsion=True, pk_inf=None):
-        """n x Signature::verify -> (status uint8[n], n_fail)."""
+    def verify_many(self, sigs, pks, msgs, offsets=None, check_torsion=True, pk_inf=None, mode=None):
+        """n x Signature::verify -> (status uint8[n], n_fail).  mode: None/"auto" (wave-per-signature
+        kernel for small batches, lane-per-signature kernels for large ones), "lane" or "coop"."""
         sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
         n = sigs.shape[0]
         assert pks.shape[0] == n
@@ -179,9 +183,9 @@ class Engine:
         inf = _np_u8(pk_inf) if pk_inf is not None else None
         status = np.full(n, 255, dtype=np.uint8)
         nfail = C.c_uint64(0)
+        flags = (FLAG_CHECK_TORSION if check_torsion else 0) | _MODE_FLAGS[mode]
         _check(_lib.ssa_verify_many(self._ctx, _ptr(sigs), _ptr(pks), _ptr(inf), _ptr(m), _ptr(off), stride,
-                                    mlen, n, FLAG_CHECK_TORSION if check_torsion else 0, _ptr(status),
-                                    C.byref(nfail)), "ssa_verify_many")
+                                    mlen, n, flags, _ptr(status), C.byref(nfail)), "ssa_verify_many")
         return status, int(nfail.value)
 
     def verify_batch_status(self, sigs, pks, msgs, offsets=None, check_torsion=False):
@@ -274,11 +278,11 @@ class Engine:
         _check(_lib.ssa_ctx_sync(self._ctx), "ssa_ctx_sync")
 
     def verify_many_device(self, d_sigs, d_pks, d_msgs, n, msg_len, d_status, d_nfail, msg_stride=None,
-                           d_offsets=0, d_pk_inf=0, check_torsion=False):
+                           d_offsets=0, d_pk_inf=0, check_torsion=False, mode=None):
+        flags = (FLAG_CHECK_TORSION if check_torsion else 0) | _MODE_FLAGS[mode]
         _check(_lib.ssa_verify_many_device(self._ctx, d_sigs, d_pks, d_pk_inf or None, d_msgs, d_offsets or None,
                                            msg_stride if msg_stride is not None else msg_len, msg_len, n,
-                                           FLAG_CHECK_TORSION if check_torsion else 0, d_status, d_nfail),
-               "ssa_verify_many_device")
+                                           flags, d_status, d_nfail), "ssa_verify_many_device")
 
     def keygen_sign_many_device(self, d_sks, d_nonces, d_msgs, n, msg_len, d_pks, d_sigs, msg_stride=None,
                                 d_offsets=0):

@@ -62,6 +62,7 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     HIP_TRY(hipSetDevice(device));
     ssa_ctx *ctx = new ssa_ctx();
     ctx->device = device;
+    if (const char *cm = std::getenv("SSA_COOP_MAX_N")) ctx->coop_max_n = (size_t)std::strtoull(cm, nullptr, 10);
     if (const char *vb = std::getenv("SSA_VERIFY_BLOCK")) {
         const int v = std::atoi(vb);
         if (v == 64 || v == 128 || v == 256) ctx->verify_block = (unsigned)v;
@@ -208,9 +209,17 @@ extern "C" int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const
                                               : (unsigned long long *)ctx->ws_fail.p;
     HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), ctx->stream));
     if (n == 0) return 0;
+    MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
+    // small batches: one wave per signature (low latency); large ones: one lane per signature (throughput)
+    const bool coop = (flags & SSA_FLAG_FORCE_COOP) || (!(flags & SSA_FLAG_FORCE_LANE) && n <= ctx->coop_max_n);
+    if (coop) {
+        return timed_launch(ctx, "ssa_k_verify_coop", [&] {
+            hipLaunchKernelGGL(ssa_k_verify_coop, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_params, d_sigs,
+                               d_pks, d_pk_inf, mv, (const u64 *)ctx->d_gtab, n, flags, d_status_out, d_fail);
+        });
+    }
     if (ctx->ws_h.reserve(n * 4 * sizeof(u64))) return SSA_ERR_HIP;
     if (ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
-    MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
     int rc = timed_launch(ctx, "ssa_k_hash", [&] {
         hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
                            d_sigs, d_pks, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr);

@@ -1,0 +1,419 @@
+// Wave-cooperative arithmetic: ONE WAVE works on ONE point / ONE signature.
+//
+// The per-lane kernels (ssa_kernels.cuh) need ~65 k lanes to fill the chip and take ~8 ms per call
+// however small the batch is, because a lane runs its ~330 point operations serially.  Here the 36
+// products of an Fp6 multiplication go to 36 lanes, six lanes add up the columns and reduce, operands
+// live in LDS.  Used for (1) the sequential tail of the MSM reduction (ssa_msm.hip) and (2) the
+// low-latency verification kernel ssa_k_verify_coop (small batches, single Signature::verify calls).
+//
+// Every function here must be called by ALL 64 threads of a one-wave block (blockDim.x == 64);
+// Fp6 values are LDS slots addressed by index, booleans returned are wave-uniform.
+#pragma once
+// (included at the end of ssa_kernels.cuh: uses its byte loaders, msg_felt and status codes)
+
+namespace ssa {
+
+constexpr int COOP_SLOTS = 72;
+
+struct CoopLds {
+    u64 slot[COOP_SLOTS][6];  // Fp6 values
+    u64 part[6][6][2];        // 128-bit products grouped by output coefficient
+    u64 b7[6];                // 7 * b_j for the wrapped terms
+    u64 st[2][12];            // Rescue state planes
+};
+
+#define COOP_FN __device__ __forceinline__
+
+COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane) {
+    if (lane < 6) L.b7[lane] = fp_mul_small(L.slot[b][lane], 7u);
+    __syncthreads();
+    if (lane < 36) {
+        const u32 i = lane / 6, j = lane % 6;
+        u32 k = i + j;
+        u64 bb = L.slot[b][j];
+        if (k >= 6) {
+            k -= 6;
+            bb = L.b7[j];
+        }
+        u64 lo, hi;
+        mul64x64(L.slot[a][i], bb, lo, hi);
+        L.part[k][i][0] = lo;
+        L.part[k][i][1] = hi;
+    }
+    __syncthreads();
+    if (lane < 6) {
+        u64 lo = 0, hi = 0, top = 0;
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const u64 plo = L.part[lane][t][0], phi = L.part[lane][t][1];
+            const u64 nlo = lo + plo;
+            const u64 c0 = nlo < plo;
+            const u64 nh1 = hi + phi;
+            const u64 c1 = nh1 < phi;
+            const u64 nh2 = nh1 + c0;
+            const u64 c2 = nh2 < c0;
+            lo = nlo;
+            hi = nh2;
+            top += c1 + c2;
+        }
+        L.slot[dst][lane] = fp_reduce_parts(lo, lo32(hi), (u64)hi32(hi) + (top << 32));
+    }
+    __syncthreads();
+}
+COOP_FN void coop_add(CoopLds &L, int dst, int a, int b, u32 lane) {
+    if (lane < 6) L.slot[dst][lane] = fp_add(L.slot[a][lane], L.slot[b][lane]);
+    __syncthreads();
+}
+COOP_FN void coop_sub(CoopLds &L, int dst, int a, int b, u32 lane) {
+    if (lane < 6) L.slot[dst][lane] = fp_sub(L.slot[a][lane], L.slot[b][lane]);
+    __syncthreads();
+}
+COOP_FN void coop_neg(CoopLds &L, int dst, int a, u32 lane) {
+    if (lane < 6) L.slot[dst][lane] = fp_neg(L.slot[a][lane]);
+    __syncthreads();
+}
+COOP_FN void coop_copy(CoopLds &L, int dst, int a, u32 lane) {
+    if (lane < 6) L.slot[dst][lane] = L.slot[a][lane];
+    __syncthreads();
+}
+COOP_FN void coop_set(CoopLds &L, int dst, u64 c0, u32 lane) {  // dst = c0 (element of Fp)
+    if (lane < 6) L.slot[dst][lane] = lane == 0 ? c0 : 0ull;
+    __syncthreads();
+}
+COOP_FN void coop_mul_fp(CoopLds &L, int dst, int a, u64 s, u32 lane) {
+    if (lane < 6) L.slot[dst][lane] = fp_mul(L.slot[a][lane], s);
+    __syncthreads();
+}
+COOP_FN bool coop_is_zero(CoopLds &L, int a, u32 lane) {
+    const bool z = lane < 6 ? fp_is_zero(L.slot[a][lane]) : true;
+    return __all(z);
+}
+COOP_FN bool coop_eq(CoopLds &L, int a, int b, u32 lane) {
+    const bool e = lane < 6 ? fp_eq(L.slot[a][lane], L.slot[b][lane]) : true;
+    return __all(e);
+}
+
+// dst = a^-1 through the norm to Fp (a != 0); uses scratch slots t0, t1, t2 (all distinct from a)
+COOP_FN void coop_inv(CoopLds &L, int dst, int a, int t0, int t1, int t2, u32 lane) {
+    // t0 = frob_1(a) * frob_2(a) * ... * frob_5(a)
+    if (lane < 6) {
+        L.slot[t0][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * 1);
+        L.slot[t1][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * 2);
+    }
+    __syncthreads();
+    coop_mul(L, t0, t0, t1, lane);
+#pragma unroll 1
+    for (int k = 3; k <= 5; k++) {
+        if (lane < 6) L.slot[t1][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * k);
+        __syncthreads();
+        coop_mul(L, t0, t0, t1, lane);
+    }
+    coop_mul(L, t2, a, t0, lane);                 // norm: only c0 is non-zero
+    const u64 ninv = fp_inv(L.slot[t2][0]);       // every lane computes the same Fp inverse
+    coop_mul_fp(L, dst, t0, ninv, lane);
+}
+
+// (X, Y, Z) <- 2 (X, Y, Z), dbl-2007-bl with a = 1; t[0..8] are nine scratch slots
+COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lane) {
+    const int XX = t[0], YY = t[1], YYYY = t[2], ZZ = t[3], T = t[4], S = t[5], M = t[6], U = t[7], V = t[8];
+    coop_mul(L, XX, X, X, lane);
+    coop_mul(L, YY, Y, Y, lane);
+    coop_mul(L, YYYY, YY, YY, lane);
+    coop_mul(L, ZZ, Z, Z, lane);
+    coop_add(L, T, X, YY, lane);
+    coop_mul(L, T, T, T, lane);
+    coop_sub(L, T, T, XX, lane);
+    coop_sub(L, T, T, YYYY, lane);
+    coop_add(L, S, T, T, lane);            // S = 2((X+YY)^2 - XX - YYYY)
+    coop_add(L, M, XX, XX, lane);
+    coop_add(L, M, M, XX, lane);
+    coop_mul(L, U, ZZ, ZZ, lane);
+    coop_add(L, M, M, U, lane);            // M = 3XX + ZZ^2
+    coop_add(L, U, Y, Z, lane);
+    coop_mul(L, U, U, U, lane);
+    coop_sub(L, U, U, YY, lane);
+    coop_sub(L, Z, U, ZZ, lane);           // Z3 = (Y+Z)^2 - YY - ZZ
+    coop_mul(L, V, M, M, lane);
+    coop_sub(L, V, V, S, lane);
+    coop_sub(L, X, V, S, lane);            // X3 = M^2 - 2S
+    coop_sub(L, V, S, X, lane);
+    coop_mul(L, V, M, V, lane);
+    coop_add(L, U, YYYY, YYYY, lane);
+    coop_add(L, U, U, U, lane);
+    coop_add(L, U, U, U, lane);            // 8 YYYY
+    coop_sub(L, Y, V, U, lane);            // Y3 = M (S - X3) - 8 YYYY
+}
+
+// (X, Y, Z) <- (X, Y, Z) + (QX, QY) affine, (0, 0) = identity; same case analysis as jac_madd
+COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, const int *t, u32 lane) {
+    const int Z1Z1 = t[0], U2 = t[1], S2 = t[2], H = t[3], R = t[4], HH = t[5], HHH = t[6], V = t[7], W = t[8];
+    const bool p_inf = coop_is_zero(L, Z, lane);
+    const bool q_inf = coop_is_zero(L, QX, lane) && coop_is_zero(L, QY, lane);
+    if (q_inf) return;
+    if (p_inf) {
+        coop_copy(L, X, QX, lane);
+        coop_copy(L, Y, QY, lane);
+        coop_set(L, Z, 1ull, lane);
+        return;
+    }
+    coop_mul(L, Z1Z1, Z, Z, lane);
+    coop_mul(L, U2, QX, Z1Z1, lane);
+    coop_mul(L, S2, QY, Z, lane);
+    coop_mul(L, S2, S2, Z1Z1, lane);
+    coop_sub(L, H, U2, X, lane);
+    coop_sub(L, R, S2, Y, lane);
+    if (coop_is_zero(L, H, lane)) {
+        if (coop_is_zero(L, R, lane)) {
+            coop_jac_dbl(L, X, Y, Z, t, lane);      // p == q
+        } else {
+            coop_set(L, Z, 0ull, lane);             // p == -q
+        }
+        return;
+    }
+    coop_mul(L, HH, H, H, lane);
+    coop_mul(L, HHH, H, HH, lane);
+    coop_mul(L, V, X, HH, lane);
+    coop_mul(L, W, R, R, lane);
+    coop_sub(L, W, W, HHH, lane);
+    coop_sub(L, W, W, V, lane);
+    coop_sub(L, X, W, V, lane);                     // X3 = R^2 - HHH - 2V
+    coop_sub(L, V, V, X, lane);
+    coop_mul(L, V, R, V, lane);
+    coop_mul(L, W, Y, HHH, lane);
+    coop_sub(L, Y, V, W, lane);                     // Y3 = R (V - X3) - Y1 HHH
+    coop_mul(L, Z, Z, H, lane);                     // Z3 = Z1 H
+}
+
+// ------------------------------------------------------------------------------------------------
+// Signature::verify for ONE signature by ONE wave (reference src/signature.rs:181-205): the same
+// algorithm as ssa_k_hash + ssa_k_verify (affine table 1P..8P, signed 4-bit windows, comb for G,
+// x-only compare, optional [q]P == O first), every Fp6 operation spread over the wave.
+namespace coop_slots {
+enum : int { AX = 0, AY, AZ, QX, QY, PX, PY, SX, T0, I0 = T0 + 9, I1, I2, TAB };   // TAB: 8 x (X, Y, Z, C)
+}
+
+// Rescue-Prime permutation on the 12 lanes 0..11; state in plane L.st[0], L.st[1] is scratch
+COOP_FN void coop_rescue_permutation(CoopLds &L, const DevParams *__restrict__ prm, u32 lane) {
+    const u32 nr = prm->n_rounds;
+    const bool small = (prm->flags & PRM_FLAG_SMALL_MDS) != 0;
+    u64 *S = L.st[0], *T = L.st[1];
+#pragma unroll 1
+    for (u32 r = 0; r < nr; r++) {
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            u64 *src = half ? T : S, *dst = half ? S : T;
+            if (lane < 12) src[lane] = half ? inv_sbox(src[lane]) : sbox(src[lane]);
+            __syncthreads();
+            if (lane < 12) {
+                const u64 *row = prm->mds + lane * 12;
+                const u64 *ark = (half ? prm->ark2 : prm->ark1) + 12 * r;
+                fp_acc acc;
+                acc_zero(acc);
+#pragma unroll 1
+                for (int j = 0; j < 12; j++) {
+                    if (small) acc_mac32(acc, src[j], (u32)row[j]);
+                    else acc_mac(acc, src[j], row[j]);
+                }
+                dst[lane] = fp_add(acc_reduce(acc), ark[lane]);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// hash_message (src/signature.rs:274-306) of the signature staged in slots SX / PX / PY -> scalar h
+COOP_FN sc256 coop_hash_message(CoopLds &L, const DevParams *__restrict__ prm, const u8 *m, u32 len, u32 lane) {
+    using namespace coop_slots;
+    const u32 nmsg = (len + 6u) / 7u, n_felts = 13u + nmsg;
+    u64 *S = L.st[0];
+    if (lane < 12) S[lane] = ((int)lane == prm->cap_len_idx) ? (u64)n_felts : 0ull;
+    __syncthreads();
+    const u32 rate_off = prm->rate_off;
+    const bool pad1 = prm->pad_mode == 1;
+    const u32 n_blocks = pad1 ? n_felts / 8 + 1 : (n_felts + 7) / 8;
+#pragma unroll 1
+    for (u32 b = 0; b < n_blocks; b++) {
+        if (lane < 8) {
+            const u32 idx = 8 * b + lane;
+            u64 v = 0;
+            bool have = false;
+            if (idx < n_felts) {
+                have = true;
+                if (idx < 6) v = L.slot[SX][idx];
+                else if (idx < 12) v = L.slot[PX][idx - 6];
+                else if (idx == 12) v = L.slot[PY][0];
+                else v = msg_felt(m, len, idx - 13u);
+            } else if (pad1 && idx == n_felts) {
+                have = true;
+                v = 1ull;
+            }
+            if (have) S[rate_off + lane] = fp_add(S[rate_off + lane], v);
+        }
+        __syncthreads();
+        coop_rescue_permutation(L, prm, lane);
+    }
+    sc256 h;
+#pragma unroll
+    for (int k = 0; k < 4; k++) h.w[k] = fp_canon(S[prm->digest_off + k]);
+    __syncthreads();
+    return sc_reduce256(h);    // Scalar::from_bits_vartime, src/signature.rs:189-192
+}
+
+// affine multiples 1P..8P into the TAB slots (rows of X, Y, Z, C); identity multiples become (0, 0)
+COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane) {
+    using namespace coop_slots;
+    int t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = T0 + k;
+    auto row = [](int e, int f) { return TAB + 4 * e + f; };
+    if (p_inf) {
+#pragma unroll 1
+        for (int e = 0; e < 8; e++) {
+            coop_set(L, row(e, 0), 0ull, lane);
+            coop_set(L, row(e, 1), 0ull, lane);
+        }
+        return;
+    }
+    coop_copy(L, row(0, 0), PX, lane);
+    coop_copy(L, row(0, 1), PY, lane);
+    coop_set(L, row(0, 2), 1ull, lane);
+    // (source row, operation): 2P = dbl 1P, 3P = 2P + P, 4P = dbl 2P, 5P = 4P + P, 6P = dbl 3P, 7P = 6P + P, 8P = dbl 4P
+    const int src[7] = {0, 1, 1, 3, 2, 5, 3};
+    const bool is_add[7] = {false, true, false, true, false, true, false};
+#pragma unroll 1
+    for (int e = 1; e < 8; e++) {
+        const int s = src[e - 1];
+        coop_copy(L, AX, row(s, 0), lane);
+        coop_copy(L, AY, row(s, 1), lane);
+        coop_copy(L, AZ, row(s, 2), lane);
+        if (is_add[e - 1]) coop_jac_madd(L, AX, AY, AZ, PX, PY, t, lane);
+        else coop_jac_dbl(L, AX, AY, AZ, t, lane);
+        coop_copy(L, row(e, 0), AX, lane);
+        coop_copy(L, row(e, 1), AY, lane);
+        coop_copy(L, row(e, 2), AZ, lane);
+    }
+    // Montgomery's trick over the (non-zero) Z's
+    coop_set(L, QX, 1ull, lane);                             // running prefix product
+#pragma unroll 1
+    for (int e = 1; e < 8; e++) {
+        if (coop_is_zero(L, row(e, 2), lane)) coop_set(L, QY, 1ull, lane);
+        else coop_copy(L, QY, row(e, 2), lane);
+        coop_mul(L, QX, QX, QY, lane);
+        coop_copy(L, row(e, 3), QX, lane);
+    }
+    coop_inv(L, QX, QX, I0, I1, I2, lane);                   // QX = 1 / prod Z
+#pragma unroll 1
+    for (int e = 7; e >= 1; e--) {
+        const bool zero = coop_is_zero(L, row(e, 2), lane);
+        if (zero) coop_set(L, QY, 1ull, lane);
+        else coop_copy(L, QY, row(e, 2), lane);
+        if (e > 1) coop_mul(L, I0, QX, row(e - 1, 3), lane); // 1 / Z_e
+        else coop_copy(L, I0, QX, lane);
+        coop_mul(L, QX, QX, QY, lane);
+        coop_mul(L, I1, I0, I0, lane);                       // Zinv^2
+        coop_mul(L, row(e, 0), row(e, 0), I1, lane);
+        coop_mul(L, I1, I1, I0, lane);                       // Zinv^3
+        coop_mul(L, row(e, 1), row(e, 1), I1, lane);
+        if (zero) {
+            coop_set(L, row(e, 0), 0ull, lane);
+            coop_set(L, row(e, 1), 0ull, lane);
+        }
+    }
+}
+
+// (AX, AY, AZ) <- [k] P from the table, k < 2^255
+COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane) {
+    using namespace coop_slots;
+    int t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = T0 + i;
+    const sc256 kr = sc_recode_offset(k);
+    coop_set(L, AX, 1ull, lane);
+    coop_set(L, AY, 1ull, lane);
+    coop_set(L, AZ, 0ull, lane);
+    const u32 top = sc_nibble(kr, 63u);
+    if (top != 0) {
+        const int e = (int)top - 1;
+        if (!(coop_is_zero(L, TAB + 4 * e, lane) && coop_is_zero(L, TAB + 4 * e + 1, lane))) {
+            coop_copy(L, AX, TAB + 4 * e, lane);
+            coop_copy(L, AY, TAB + 4 * e + 1, lane);
+            coop_set(L, AZ, 1ull, lane);
+        }
+    }
+#pragma unroll 1
+    for (int w = 62; w >= 0; w--) {
+#pragma unroll 1
+        for (int d = 0; d < 4; d++) coop_jac_dbl(L, AX, AY, AZ, t, lane);
+        const int digit = (int)sc_nibble(kr, (u32)w) - 8;
+        if (digit != 0) {
+            const int e = (digit < 0 ? -digit : digit) - 1;
+            coop_copy(L, QX, TAB + 4 * e, lane);
+            if (digit < 0) coop_neg(L, QY, TAB + 4 * e + 1, lane);
+            else coop_copy(L, QY, TAB + 4 * e + 1, lane);
+            coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane);
+        }
+    }
+}
+
+COOP_FN u32 coop_verify_one(CoopLds &L, const DevParams *__restrict__ prm, const u8 *__restrict__ sig,
+                            const u8 *__restrict__ pk, bool inf, const u8 *__restrict__ m, u32 len,
+                            const u64 *__restrict__ gtab, u32 flags, u32 lane) {
+    using namespace coop_slots;
+    int t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = T0 + i;
+    // stage and validate the inputs
+    bool ok_lane = true;
+    if (lane < 6) {
+        const u64 xs = ld_u64_le(sig + 8 * lane), px = ld_u64_le(pk + 8 * lane), py = ld_u64_le(pk + 48 + 8 * lane);
+        L.slot[SX][lane] = xs;
+        L.slot[PX][lane] = px;
+        L.slot[PY][lane] = py;
+        ok_lane = xs < FP_P && px < FP_P && py < FP_P;
+    }
+    const sc256 e = ld_sc(sig + 49);
+    bool ok = __all(ok_lane) && !sc_geq_q(e);
+    __syncthreads();
+    if (ok && !inf) {   // y^2 == x^3 + x + (u + 395)
+        coop_mul(L, T0, PX, PX, lane);
+        coop_mul(L, T0, T0, PX, lane);
+        coop_add(L, T0, T0, PX, lane);
+        if (lane < 2) L.slot[T0][lane] = fp_add(L.slot[T0][lane], lane == 0 ? 395ull : 1ull);
+        __syncthreads();
+        coop_mul(L, T0 + 1, PY, PY, lane);
+        ok = coop_eq(L, T0, T0 + 1, lane);
+    }
+    if (!ok) return ST_MALFORMED;
+    const sc256 h = coop_hash_message(L, prm, m, len, lane);
+    coop_build_table(L, inf, lane);
+    if (flags & 1u) {   // is_torsion_free, src/signature.rs:182-184
+        sc256 q;
+#pragma unroll
+        for (int k = 0; k < 4; k++) q.w[k] = SC_Q(k);
+        coop_mul_table(L, q, lane);
+        if (!coop_is_zero(L, AZ, lane)) return ST_INVALID_PK;
+    }
+    coop_mul_table(L, h, lane);                                   // [h]P
+#pragma unroll 1
+    for (int w = 0; w < 16; w++) {                                // + [e]G, src/signature.rs:196-198
+        const u32 d = sc_win16(e, (u32)w);
+        if (d != 0) {
+            const u64 *rowp = gtab + (((size_t)w << 16) + d) * 12;
+            if (lane < 6) L.slot[QX][lane] = rowp[lane];
+            else if (lane < 12) L.slot[QY][lane - 6] = rowp[lane];
+            __syncthreads();
+            coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane);
+        }
+    }
+    bool eq;
+    if (coop_is_zero(L, AZ, lane)) {
+        eq = coop_is_zero(L, SX, lane);                           // the identity's x is taken as 0
+    } else {
+        coop_mul(L, T0, AZ, AZ, lane);
+        coop_mul(L, T0, SX, T0, lane);
+        eq = coop_eq(L, AX, T0, lane);                            // X == x * Z^2, src/signature.rs:200
+    }
+    return eq ? ST_OK : ST_INVALID_SIG;
+}
+
+}  // namespace ssa

@@ -709,3 +709,30 @@ __global__ void __launch_bounds__(256) ssa_k_f6mul_bench(u64 *out, u64 seed, int
 #endif  // SSA_NO_KERNELS
 
 }  // namespace ssa
+
+// wave-cooperative path (device code only; the host-compiled unit tests leave it out)
+#ifndef SSA_NO_COOP
+#include "ssa_coop.cuh"
+
+#ifndef SSA_NO_KERNELS
+namespace ssa {
+// Low-latency verification: one wave (one 64-thread block) per signature.
+__global__ void __launch_bounds__(64)
+ssa_k_verify_coop(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
+                  const u8 *__restrict__ pk_inf, MsgView mv, const u64 *__restrict__ gtab, size_t n, u32 flags,
+                  u8 *__restrict__ status_out, unsigned long long *__restrict__ n_fail) {
+    __shared__ CoopLds L;
+    const size_t i = blockIdx.x;
+    if (i >= n) return;
+    u32 len;
+    const u8 *m = msg_ptr(mv, i, len);
+    const u32 st = coop_verify_one(L, prm, sigs + 81 * i, pks + 96 * i, pk_inf && pk_inf[i], m, len, gtab, flags,
+                                   threadIdx.x);
+    if (threadIdx.x == 0) {
+        status_out[i] = (u8)st;
+        if (st != ST_OK) atomicAdd(n_fail, 1ull);
+    }
+}
+}  // namespace ssa
+#endif  // SSA_NO_KERNELS
+#endif  // SSA_NO_COOP

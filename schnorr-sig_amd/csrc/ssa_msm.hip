@@ -208,99 +208,21 @@ msm_k_tree(const u64 *__restrict__ in, u32 windows, u32 count, u32 group, u64 *_
     st_jac(out + 18 * (size_t)t, acc);
 }
 
-// ---- wave-cooperative Fp6 arithmetic for the one sequential chain of the reduction ---------------
+// ---- the one sequential chain of the reduction ---------------------------------------------------
 // Shifting window j by 2^(c j) is a chain of up to 240 dependent doublings.  A lone lane runs it at a
 // few percent of a SIMD's issue rate (measured: ~80 us per doubling), so one WAVE works on one point
-// instead: the 36 products of an Fp6 multiplication go to 36 lanes, six lanes add up the columns and
-// reduce; operands live in LDS.  Only doubling is needed here.
-struct CoopLds {
-    u64 slot[16][6];      // Fp6 values
-    u64 part[6][6][2];    // 128-bit products grouped by output coefficient
-    u64 b7[6];            // 7 * b_j for the wrapped terms
-};
-
-__device__ __forceinline__ void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane) {
-    if (lane < 6) L.b7[lane] = fp_mul_small(L.slot[b][lane], 7u);
-    __syncthreads();
-    if (lane < 36) {
-        const u32 i = lane / 6, j = lane % 6;
-        u32 k = i + j;
-        u64 bb = L.slot[b][j];
-        if (k >= 6) {
-            k -= 6;
-            bb = L.b7[j];
-        }
-        u64 lo, hi;
-        mul64x64(L.slot[a][i], bb, lo, hi);
-        L.part[k][i][0] = lo;
-        L.part[k][i][1] = hi;
-    }
-    __syncthreads();
-    if (lane < 6) {
-        u64 lo = 0, hi = 0, top = 0;
-#pragma unroll
-        for (int t = 0; t < 6; t++) {
-            const u64 plo = L.part[lane][t][0], phi = L.part[lane][t][1];
-            const u64 nlo = lo + plo;
-            const u64 c0 = nlo < plo;
-            const u64 nh1 = hi + phi;
-            const u64 c1 = nh1 < phi;
-            const u64 nh2 = nh1 + c0;
-            const u64 c2 = nh2 < c0;
-            lo = nlo;
-            hi = nh2;
-            top += c1 + c2;
-        }
-        L.slot[dst][lane] = fp_reduce_parts(lo, lo32(hi), (u64)hi32(hi) + (top << 32));
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void coop_add(CoopLds &L, int dst, int a, int b, u32 lane) {
-    if (lane < 6) L.slot[dst][lane] = fp_add(L.slot[a][lane], L.slot[b][lane]);
-    __syncthreads();
-}
-__device__ __forceinline__ void coop_sub(CoopLds &L, int dst, int a, int b, u32 lane) {
-    if (lane < 6) L.slot[dst][lane] = fp_sub(L.slot[a][lane], L.slot[b][lane]);
-    __syncthreads();
-}
-
-// window j (one wave per window): W_j <- [2^(c j)] W_j with cooperative dbl-2007-bl doublings
+// (wave-cooperative Fp6 arithmetic, ssa_coop.cuh): ~5 us per doubling.
 __global__ void __launch_bounds__(64)
 msm_k_shift(const u64 *__restrict__ win_in, MsmShape sh, u64 *__restrict__ win_out) {
     __shared__ CoopLds L;
     const u32 j = blockIdx.x, lane = threadIdx.x;
-    enum { X = 0, Y, Z, XX, YY, YYYY, ZZ, T, S, M, U, V };
+    int t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = 3 + k;
     if (lane < 18) L.slot[lane / 6][lane % 6] = win_in[18 * (size_t)j + lane];
     __syncthreads();
 #pragma unroll 1
-    for (u32 s = 0; s < j * sh.c; s++) {
-        coop_mul(L, XX, X, X, lane);
-        coop_mul(L, YY, Y, Y, lane);
-        coop_mul(L, YYYY, YY, YY, lane);
-        coop_mul(L, ZZ, Z, Z, lane);
-        coop_add(L, T, X, YY, lane);
-        coop_mul(L, T, T, T, lane);
-        coop_sub(L, T, T, XX, lane);
-        coop_sub(L, T, T, YYYY, lane);
-        coop_add(L, S, T, T, lane);            // S = 2((X+YY)^2 - XX - YYYY)
-        coop_add(L, M, XX, XX, lane);
-        coop_add(L, M, M, XX, lane);
-        coop_mul(L, U, ZZ, ZZ, lane);
-        coop_add(L, M, M, U, lane);            // M = 3XX + ZZ^2  (a = 1)
-        coop_add(L, U, Y, Z, lane);            // (Y + Z) before X, Y, Z are overwritten
-        coop_mul(L, U, U, U, lane);
-        coop_sub(L, U, U, YY, lane);
-        coop_sub(L, Z, U, ZZ, lane);           // Z3 = (Y+Z)^2 - YY - ZZ
-        coop_mul(L, V, M, M, lane);
-        coop_sub(L, V, V, S, lane);
-        coop_sub(L, X, V, S, lane);            // X3 = M^2 - 2S
-        coop_sub(L, V, S, X, lane);
-        coop_mul(L, V, M, V, lane);
-        coop_add(L, U, YYYY, YYYY, lane);
-        coop_add(L, U, U, U, lane);
-        coop_add(L, U, U, U, lane);            // 8 YYYY
-        coop_sub(L, Y, V, U, lane);            // Y3 = M (S - X3) - 8 YYYY
-    }
+    for (u32 s = 0; s < j * sh.c; s++) coop_jac_dbl(L, 0, 1, 2, t, lane);
     if (lane < 18) win_out[18 * (size_t)j + lane] = L.slot[lane / 6][lane % 6];
 }
 

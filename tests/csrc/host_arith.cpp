@@ -4,6 +4,7 @@
 // machine without a GPU.  The shipped library never executes this code on the CPU.
 //   hipcc --cuda-host-only -x hip -O2 -shared -fPIC host_arith.cpp -o libhost_arith.so
 #define SSA_NO_KERNELS 1
+#define SSA_NO_COOP 1
 #include <cstring>
 #include "../../schnorr-sig_amd/csrc/ssa_kernels.cuh"
 

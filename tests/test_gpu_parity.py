@@ -711,10 +711,11 @@ def test_fuzz_mixed_batch_vs_oracle(engine, oracle):
         elif k == 8:
             sigs[i, 0] ^= 1           # R.x changed: canonical, (almost surely) not the signer's R
     for torsion in (True, False):
-        st, nf = engine.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf)
         want = oracle.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf)
-        assert (st == want).all(), np.nonzero(st != want)[0][:10]
-        assert nf == int((want != 0).sum())
+        for mode in ("lane", "coop"):       # throughput kernels and the wave-per-signature kernel
+            st, nf = engine.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf, mode=mode)
+            assert (st == want).all(), (mode, np.nonzero(st != want)[0][:10])
+            assert nf == int((want != 0).sum())
         assert set(np.unique(st)) <= {0, 1, 2, 3} and (st == 0).sum() > n // 3
 
 
@@ -807,3 +808,77 @@ def test_multi_device_sharding_single_process(engine):
         assert nf2 == 0 and (st2 == 0).all()
     finally:
         multi.close()
+
+
+# ---------------------------------------------------------------- wave-per-signature (low-latency) kernel
+@pytest.mark.parametrize("mode", ["lane", "coop"])
+def test_both_kernel_families_on_the_edge_cases(engine, oracle, mode):
+    """Every exceptional-case input of this file through BOTH kernel families: one lane per signature
+    (throughput) and one wave per signature (latency)."""
+    import pymodel as m
+    rng = np.random.default_rng(61)
+    prm = m.default_params()
+    g = prm.generator()
+    sigs, pks, msgs, infs = [], [], [], []
+
+    def add(sig, pk96, msg, inf=0):
+        sigs.append(sig); pks.append(pk96); msgs.append(msg); infs.append(inf)
+
+    def pkb(p):
+        return m.fp6_to_bytes48(p[0]) + m.fp6_to_bytes48(p[1])
+    # honest signatures over the chunking-relevant message lengths
+    for L in (0, 1, 6, 7, 8, 13, 14, 24, 48, 80, 160):
+        msg = bytes(rng.integers(0, 256, size=L, dtype=np.uint8))
+        sig, pk = m.sign(int(rng.integers(1, 2**62)), int(rng.integers(1, 2**62)), msg, prm)
+        add(sig, pkb(pk), msg)
+        add(sig[:49] + bytes([sig[49] ^ 1]) + sig[50:], pkb(pk), msg)
+    # adversarial e: [h]P + [e]G lands on / opposite comb-table points
+    for k in (1, 2, 65536, Q - 1):
+        pk = m.pt_mul(k, g)
+        rx = m.pt_mul(12345, g)[0]
+        h = m.scalar_from_digest(m.hash_message(rx, pk, b"adv", prm))
+        for target in (0, 1, 2, 65536, 65537, Q - 1):
+            e = (target - h * k) % Q
+            add(m.fp6_to_bytes48(rx) + b"\0" + e.to_bytes(32, "little"), pkb(pk), b"adv")
+    # small-order and non-subgroup keys, identity key, malformed encodings
+    for p in [m.FIXTURE_SMALL_ORDER_PK] + [m.SMALL_ORDER_POINTS[o] for o in (2, 5, 10)]:
+        for t in range(3):
+            rx = m.pt_mul(777 + t, g)[0]
+            add(m.fp6_to_bytes48(rx) + b"\0" + int(rng.integers(0, 2**62)).to_bytes(32, "little"), pkb(p), b"xyz")
+    r = int(rng.integers(1, 2**62))
+    add(m.fp6_to_bytes48(m.pt_mul(r, g)[0]) + b"\0" + r.to_bytes(32, "little"), bytes(96), b"identity key", 1)
+    good_sig, good_pk = m.sign(5, 7, b"m", prm)
+    add(b"\xff" * 8 + good_sig[8:], pkb(good_pk), b"m")
+    add(good_sig[:49] + b"\xff" * 32, pkb(good_pk), b"m")
+    add(good_sig, pkb(good_pk)[:95] + bytes([pkb(good_pk)[95] ^ 1]), b"m")
+    add(bytes(48) + b"\x80" + good_sig[49:], pkb(good_pk), b"m")
+    n = len(sigs)
+    S = np.frombuffer(b"".join(sigs), dtype=np.uint8).reshape(n, 81)
+    P_ = np.frombuffer(b"".join(pks), dtype=np.uint8).reshape(n, 96)
+    flat = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8)
+    off = np.cumsum([0] + [len(x) for x in msgs]).astype(np.uint64)
+    inf = np.array(infs, dtype=np.uint8)
+    for torsion in (True, False):
+        st, nf = engine.verify_many(S, P_, flat, offsets=off, check_torsion=torsion, pk_inf=inf, mode=mode)
+        want = oracle.verify_many(S, P_, flat, offsets=off, check_torsion=torsion, pk_inf=inf)
+        ok = want != 3
+        ok[n - 2] = False                       # off-curve key: SSA_MALFORMED here, undefined in the reference
+        assert (st[ok] == want[ok]).all(), (mode, torsion, np.nonzero(st != want)[0])
+        assert (st[-4:-1] == 3).all()          # the three malformed rows (the off-curve key is a documented divergence)
+        assert nf == int((st != 0).sum())
+
+
+def test_auto_dispatch_agrees_across_the_threshold(engine):
+    """auto mode switches kernel family at the context's threshold; verdicts must not depend on it."""
+    rng = np.random.default_rng(62)
+    n = 12000
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, 33), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    bad = rng.permutation(n)[:100]
+    sigs[bad, 52] ^= 4
+    expect = np.zeros(n, dtype=np.uint8)
+    expect[bad] = 2
+    for cut in (1, 100, 8192, 8193, n):
+        st, nf = engine.verify_many(sigs[:cut], pks[:cut], msgs[:cut], check_torsion=True)
+        assert (st == expect[:cut]).all() and nf == int((expect[:cut] != 0).sum())
