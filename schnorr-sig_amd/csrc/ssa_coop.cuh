@@ -17,30 +17,35 @@ constexpr int COOP_SLOTS = 72;
 
 struct CoopLds {
     u64 slot[COOP_SLOTS][6];  // Fp6 values
-    u64 part[6][6][2];        // 128-bit products grouped by output coefficient
-    u64 b7[6];                // 7 * b_j for the wrapped terms
+    u64 part[6][6][3];        // products (x7 where wrapped) grouped by output coefficient: lo, hi, top
     u64 st[2][12];            // Rescue state planes
 };
 
 #define COOP_FN __device__ __forceinline__
 
 COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane) {
-    if (lane < 6) L.b7[lane] = fp_mul_small(L.slot[b][lane], 7u);
-    __syncthreads();
+    // 36 lanes: one 64x64 product each; wrapped terms (u^6 = 7) are scaled by 7 in the same lane
     if (lane < 36) {
         const u32 i = lane / 6, j = lane % 6;
         u32 k = i + j;
-        u64 bb = L.slot[b][j];
+        u64 lo, hi;
+        mul64x64(L.slot[a][i], L.slot[b][j], lo, hi);
+        u64 top = 0;
         if (k >= 6) {
             k -= 6;
-            bb = L.b7[j];
+            u64 l7lo, l7hi, h7lo, h7hi;
+            mul64x64(lo, 7ull, l7lo, l7hi);
+            mul64x64(hi, 7ull, h7lo, h7hi);
+            lo = l7lo;
+            hi = h7lo + l7hi;
+            top = h7hi + (hi < l7hi);
         }
-        u64 lo, hi;
-        mul64x64(L.slot[a][i], bb, lo, hi);
         L.part[k][i][0] = lo;
         L.part[k][i][1] = hi;
+        L.part[k][i][2] = top;
     }
     __syncthreads();
+    // 6 lanes: column sums (up to 6 * 7 * 2^128 < 2^134) and one Goldilocks reduction each
     if (lane < 6) {
         u64 lo = 0, hi = 0, top = 0;
 #pragma unroll
@@ -54,7 +59,7 @@ COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane) {
             const u64 c2 = nh2 < c0;
             lo = nlo;
             hi = nh2;
-            top += c1 + c2;
+            top += c1 + c2 + L.part[lane][t][2];
         }
         L.slot[dst][lane] = fp_reduce_parts(lo, lo32(hi), (u64)hi32(hi) + (top << 32));
     }

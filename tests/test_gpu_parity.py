@@ -879,6 +879,6 @@ def test_auto_dispatch_agrees_across_the_threshold(engine):
     sigs[bad, 52] ^= 4
     expect = np.zeros(n, dtype=np.uint8)
     expect[bad] = 2
-    for cut in (1, 100, 8192, 8193, n):
+    for cut in (1, 100, 6144, 6145, n):
         st, nf = engine.verify_many(sigs[:cut], pks[:cut], msgs[:cut], check_torsion=True)
         assert (st == expect[:cut]).all() and nf == int((expect[:cut] != 0).sum())
