@@ -53,12 +53,13 @@ while time.time() - t0 < budget:
         elif k == 8:
             sigs[i, rng.integers(0, 48)] ^= 1 << rng.integers(0, 7)
     for torsion in (True, False):
-        st, nf = eng.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf)
         want = orc.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf)
-        if not (st == want).all() or nf != int((want != 0).sum()):
-            bad = np.nonzero(st != want)[0]
-            print("MISMATCH iteration", it, "torsion", torsion, "lanes", bad[:10], st[bad[:10]], want[bad[:10]])
-            sys.exit(1)
+        for mode in ("lane", "coop"):     # both kernel families
+            st, nf = eng.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf, mode=mode)
+            if not (st == want).all() or nf != int((want != 0).sum()):
+                bad = np.nonzero(st != want)[0]
+                print("MISMATCH iteration", it, mode, "torsion", torsion, "lanes", bad[:10], st[bad[:10]], want[bad[:10]])
+                sys.exit(1)
     # decompression of the generated keys and of random x
     comp = np.zeros((min(n, 256), 49), dtype=np.uint8)
     comp[:, :48] = rng.integers(0, 256, size=(comp.shape[0], 48), dtype=np.uint8)
@@ -72,4 +73,4 @@ while time.time() - t0 < budget:
             sys.exit(1)
     total += n
     it += 1
-print("soak ok: %d iterations, %d signatures x 2 modes, %.0f s" % (it, total, time.time() - t0))
+print("soak ok: %d iterations, %d signatures x 2 torsion settings x 2 kernel families, %.0f s" % (it, total, time.time() - t0))
