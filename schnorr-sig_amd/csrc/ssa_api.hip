@@ -214,7 +214,7 @@ extern "C" int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const
     const bool coop = (flags & SSA_FLAG_FORCE_COOP) || (!(flags & SSA_FLAG_FORCE_LANE) && n <= ctx->coop_max_n);
     if (coop) {
         return timed_launch(ctx, "ssa_k_verify_coop", [&] {
-            hipLaunchKernelGGL(ssa_k_verify_coop, dim3((unsigned)n), dim3(64), 0, ctx->stream, ctx->d_params, d_sigs,
+            hipLaunchKernelGGL(ssa_k_verify_coop, dim3((unsigned)n), dim3(128), 0, ctx->stream, ctx->d_params, d_sigs,
                                d_pks, d_pk_inf, mv, (const u64 *)ctx->d_gtab, n, flags, d_status_out, d_fail);
         });
     }

@@ -17,13 +17,26 @@ constexpr int COOP_SLOTS = 72;
 
 struct CoopLds {
     u64 slot[COOP_SLOTS][6];  // Fp6 values
-    u64 part[6][6][3];        // products (x7 where wrapped) grouped by output coefficient: lo, hi, top
+    u64 part[2][6][6][3];     // per cooperating wave: products (x7 where wrapped) grouped by output coefficient
     u64 st[2][12];            // Rescue state planes
 };
 
 #define COOP_FN __device__ __forceinline__
 
-COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane) {
+// Ordering point between LDS writes and reads of different lanes.  The blocks that run this code are
+// ONE wave, so no s_barrier is needed: LDS executes a wave's instructions in order; the fence keeps the
+// compiler from moving accesses across it and waits for outstanding LDS operations.
+COOP_FN void coop_sync() {
+#ifdef SSA_COOP_USE_BARRIER
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
     // 36 lanes: one 64x64 product each; wrapped terms (u^6 = 7) are scaled by 7 in the same lane
     if (lane < 36) {
         const u32 i = lane / 6, j = lane % 6;
@@ -40,17 +53,17 @@ COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane) {
             hi = h7lo + l7hi;
             top = h7hi + (hi < l7hi);
         }
-        L.part[k][i][0] = lo;
-        L.part[k][i][1] = hi;
-        L.part[k][i][2] = top;
+        L.part[ws][k][i][0] = lo;
+        L.part[ws][k][i][1] = hi;
+        L.part[ws][k][i][2] = top;
     }
-    __syncthreads();
+    coop_sync();
     // 6 lanes: column sums (up to 6 * 7 * 2^128 < 2^134) and one Goldilocks reduction each
     if (lane < 6) {
         u64 lo = 0, hi = 0, top = 0;
 #pragma unroll
         for (int t = 0; t < 6; t++) {
-            const u64 plo = L.part[lane][t][0], phi = L.part[lane][t][1];
+            const u64 plo = L.part[ws][lane][t][0], phi = L.part[ws][lane][t][1];
             const u64 nlo = lo + plo;
             const u64 c0 = nlo < plo;
             const u64 nh1 = hi + phi;
@@ -59,146 +72,152 @@ COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane) {
             const u64 c2 = nh2 < c0;
             lo = nlo;
             hi = nh2;
-            top += c1 + c2 + L.part[lane][t][2];
+            top += c1 + c2 + L.part[ws][lane][t][2];
         }
         L.slot[dst][lane] = fp_reduce_parts(lo, lo32(hi), (u64)hi32(hi) + (top << 32));
     }
-    __syncthreads();
+    coop_sync();
 }
-COOP_FN void coop_add(CoopLds &L, int dst, int a, int b, u32 lane) {
+COOP_FN void coop_add(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
     if (lane < 6) L.slot[dst][lane] = fp_add(L.slot[a][lane], L.slot[b][lane]);
-    __syncthreads();
+    coop_sync();
 }
-COOP_FN void coop_sub(CoopLds &L, int dst, int a, int b, u32 lane) {
+COOP_FN void coop_sub(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
     if (lane < 6) L.slot[dst][lane] = fp_sub(L.slot[a][lane], L.slot[b][lane]);
-    __syncthreads();
+    coop_sync();
 }
-COOP_FN void coop_neg(CoopLds &L, int dst, int a, u32 lane) {
+COOP_FN void coop_neg(CoopLds &L, int dst, int a, u32 lane, int ws = 0) {
     if (lane < 6) L.slot[dst][lane] = fp_neg(L.slot[a][lane]);
-    __syncthreads();
+    coop_sync();
 }
-COOP_FN void coop_copy(CoopLds &L, int dst, int a, u32 lane) {
+COOP_FN void coop_copy(CoopLds &L, int dst, int a, u32 lane, int ws = 0) {
     if (lane < 6) L.slot[dst][lane] = L.slot[a][lane];
-    __syncthreads();
+    coop_sync();
 }
-COOP_FN void coop_set(CoopLds &L, int dst, u64 c0, u32 lane) {  // dst = c0 (element of Fp)
+COOP_FN void coop_set(CoopLds &L, int dst, u64 c0, u32 lane, int ws = 0) {  // dst = c0 (element of Fp)
     if (lane < 6) L.slot[dst][lane] = lane == 0 ? c0 : 0ull;
-    __syncthreads();
+    coop_sync();
 }
-COOP_FN void coop_mul_fp(CoopLds &L, int dst, int a, u64 s, u32 lane) {
+COOP_FN void coop_mul_fp(CoopLds &L, int dst, int a, u64 s, u32 lane, int ws = 0) {
     if (lane < 6) L.slot[dst][lane] = fp_mul(L.slot[a][lane], s);
-    __syncthreads();
+    coop_sync();
 }
-COOP_FN bool coop_is_zero(CoopLds &L, int a, u32 lane) {
+COOP_FN bool coop_is_zero(CoopLds &L, int a, u32 lane, int ws = 0) {
     const bool z = lane < 6 ? fp_is_zero(L.slot[a][lane]) : true;
     return __all(z);
 }
-COOP_FN bool coop_eq(CoopLds &L, int a, int b, u32 lane) {
+COOP_FN bool coop_eq(CoopLds &L, int a, int b, u32 lane, int ws = 0) {
     const bool e = lane < 6 ? fp_eq(L.slot[a][lane], L.slot[b][lane]) : true;
     return __all(e);
 }
 
 // dst = a^-1 through the norm to Fp (a != 0); uses scratch slots t0, t1, t2 (all distinct from a)
-COOP_FN void coop_inv(CoopLds &L, int dst, int a, int t0, int t1, int t2, u32 lane) {
+COOP_FN void coop_inv(CoopLds &L, int dst, int a, int t0, int t1, int t2, u32 lane, int ws = 0) {
     // t0 = frob_1(a) * frob_2(a) * ... * frob_5(a)
     if (lane < 6) {
         L.slot[t0][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * 1);
         L.slot[t1][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * 2);
     }
-    __syncthreads();
-    coop_mul(L, t0, t0, t1, lane);
+    coop_sync();
+    coop_mul(L, t0, t0, t1, lane, ws);
 #pragma unroll 1
     for (int k = 3; k <= 5; k++) {
         if (lane < 6) L.slot[t1][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * k);
-        __syncthreads();
-        coop_mul(L, t0, t0, t1, lane);
+        coop_sync();
+        coop_mul(L, t0, t0, t1, lane, ws);
     }
-    coop_mul(L, t2, a, t0, lane);                 // norm: only c0 is non-zero
+    coop_mul(L, t2, a, t0, lane, ws);                 // norm: only c0 is non-zero
     const u64 ninv = fp_inv(L.slot[t2][0]);       // every lane computes the same Fp inverse
-    coop_mul_fp(L, dst, t0, ninv, lane);
+    coop_mul_fp(L, dst, t0, ninv, lane, ws);
 }
 
 // (X, Y, Z) <- 2 (X, Y, Z), dbl-2007-bl with a = 1; t[0..8] are nine scratch slots
-COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lane) {
+COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lane, int ws = 0) {
     const int XX = t[0], YY = t[1], YYYY = t[2], ZZ = t[3], T = t[4], S = t[5], M = t[6], U = t[7], V = t[8];
-    coop_mul(L, XX, X, X, lane);
-    coop_mul(L, YY, Y, Y, lane);
-    coop_mul(L, YYYY, YY, YY, lane);
-    coop_mul(L, ZZ, Z, Z, lane);
-    coop_add(L, T, X, YY, lane);
-    coop_mul(L, T, T, T, lane);
-    coop_sub(L, T, T, XX, lane);
-    coop_sub(L, T, T, YYYY, lane);
-    coop_add(L, S, T, T, lane);            // S = 2((X+YY)^2 - XX - YYYY)
-    coop_add(L, M, XX, XX, lane);
-    coop_add(L, M, M, XX, lane);
-    coop_mul(L, U, ZZ, ZZ, lane);
-    coop_add(L, M, M, U, lane);            // M = 3XX + ZZ^2
-    coop_add(L, U, Y, Z, lane);
-    coop_mul(L, U, U, U, lane);
-    coop_sub(L, U, U, YY, lane);
-    coop_sub(L, Z, U, ZZ, lane);           // Z3 = (Y+Z)^2 - YY - ZZ
-    coop_mul(L, V, M, M, lane);
-    coop_sub(L, V, V, S, lane);
-    coop_sub(L, X, V, S, lane);            // X3 = M^2 - 2S
-    coop_sub(L, V, S, X, lane);
-    coop_mul(L, V, M, V, lane);
-    coop_add(L, U, YYYY, YYYY, lane);
-    coop_add(L, U, U, U, lane);
-    coop_add(L, U, U, U, lane);            // 8 YYYY
-    coop_sub(L, Y, V, U, lane);            // Y3 = M (S - X3) - 8 YYYY
+    coop_mul(L, XX, X, X, lane, ws);
+    coop_mul(L, YY, Y, Y, lane, ws);
+    coop_mul(L, YYYY, YY, YY, lane, ws);
+    coop_mul(L, ZZ, Z, Z, lane, ws);
+    coop_add(L, T, X, YY, lane, ws);
+    coop_mul(L, T, T, T, lane, ws);
+    coop_sub(L, T, T, XX, lane, ws);
+    coop_sub(L, T, T, YYYY, lane, ws);
+    coop_add(L, S, T, T, lane, ws);            // S = 2((X+YY)^2 - XX - YYYY)
+    coop_add(L, M, XX, XX, lane, ws);
+    coop_add(L, M, M, XX, lane, ws);
+    coop_mul(L, U, ZZ, ZZ, lane, ws);
+    coop_add(L, M, M, U, lane, ws);            // M = 3XX + ZZ^2
+    coop_add(L, U, Y, Z, lane, ws);
+    coop_mul(L, U, U, U, lane, ws);
+    coop_sub(L, U, U, YY, lane, ws);
+    coop_sub(L, Z, U, ZZ, lane, ws);           // Z3 = (Y+Z)^2 - YY - ZZ
+    coop_mul(L, V, M, M, lane, ws);
+    coop_sub(L, V, V, S, lane, ws);
+    coop_sub(L, X, V, S, lane, ws);            // X3 = M^2 - 2S
+    coop_sub(L, V, S, X, lane, ws);
+    coop_mul(L, V, M, V, lane, ws);
+    coop_add(L, U, YYYY, YYYY, lane, ws);
+    coop_add(L, U, U, U, lane, ws);
+    coop_add(L, U, U, U, lane, ws);            // 8 YYYY
+    coop_sub(L, Y, V, U, lane, ws);            // Y3 = M (S - X3) - 8 YYYY
 }
 
 // (X, Y, Z) <- (X, Y, Z) + (QX, QY) affine, (0, 0) = identity; same case analysis as jac_madd
-COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, const int *t, u32 lane) {
+COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, const int *t, u32 lane, int ws = 0) {
     const int Z1Z1 = t[0], U2 = t[1], S2 = t[2], H = t[3], R = t[4], HH = t[5], HHH = t[6], V = t[7], W = t[8];
-    const bool p_inf = coop_is_zero(L, Z, lane);
-    const bool q_inf = coop_is_zero(L, QX, lane) && coop_is_zero(L, QY, lane);
+    const bool p_inf = coop_is_zero(L, Z, lane, ws);
+    const bool q_inf = coop_is_zero(L, QX, lane, ws) && coop_is_zero(L, QY, lane, ws);
     if (q_inf) return;
     if (p_inf) {
-        coop_copy(L, X, QX, lane);
-        coop_copy(L, Y, QY, lane);
-        coop_set(L, Z, 1ull, lane);
+        coop_copy(L, X, QX, lane, ws);
+        coop_copy(L, Y, QY, lane, ws);
+        coop_set(L, Z, 1ull, lane, ws);
         return;
     }
-    coop_mul(L, Z1Z1, Z, Z, lane);
-    coop_mul(L, U2, QX, Z1Z1, lane);
-    coop_mul(L, S2, QY, Z, lane);
-    coop_mul(L, S2, S2, Z1Z1, lane);
-    coop_sub(L, H, U2, X, lane);
-    coop_sub(L, R, S2, Y, lane);
-    if (coop_is_zero(L, H, lane)) {
-        if (coop_is_zero(L, R, lane)) {
-            coop_jac_dbl(L, X, Y, Z, t, lane);      // p == q
+    coop_mul(L, Z1Z1, Z, Z, lane, ws);
+    coop_mul(L, U2, QX, Z1Z1, lane, ws);
+    coop_mul(L, S2, QY, Z, lane, ws);
+    coop_mul(L, S2, S2, Z1Z1, lane, ws);
+    coop_sub(L, H, U2, X, lane, ws);
+    coop_sub(L, R, S2, Y, lane, ws);
+    if (coop_is_zero(L, H, lane, ws)) {
+        if (coop_is_zero(L, R, lane, ws)) {
+            coop_jac_dbl(L, X, Y, Z, t, lane, ws);      // p == q
         } else {
-            coop_set(L, Z, 0ull, lane);             // p == -q
+            coop_set(L, Z, 0ull, lane, ws);             // p == -q
         }
         return;
     }
-    coop_mul(L, HH, H, H, lane);
-    coop_mul(L, HHH, H, HH, lane);
-    coop_mul(L, V, X, HH, lane);
-    coop_mul(L, W, R, R, lane);
-    coop_sub(L, W, W, HHH, lane);
-    coop_sub(L, W, W, V, lane);
-    coop_sub(L, X, W, V, lane);                     // X3 = R^2 - HHH - 2V
-    coop_sub(L, V, V, X, lane);
-    coop_mul(L, V, R, V, lane);
-    coop_mul(L, W, Y, HHH, lane);
-    coop_sub(L, Y, V, W, lane);                     // Y3 = R (V - X3) - Y1 HHH
-    coop_mul(L, Z, Z, H, lane);                     // Z3 = Z1 H
+    coop_mul(L, HH, H, H, lane, ws);
+    coop_mul(L, HHH, H, HH, lane, ws);
+    coop_mul(L, V, X, HH, lane, ws);
+    coop_mul(L, W, R, R, lane, ws);
+    coop_sub(L, W, W, HHH, lane, ws);
+    coop_sub(L, W, W, V, lane, ws);
+    coop_sub(L, X, W, V, lane, ws);                     // X3 = R^2 - HHH - 2V
+    coop_sub(L, V, V, X, lane, ws);
+    coop_mul(L, V, R, V, lane, ws);
+    coop_mul(L, W, Y, HHH, lane, ws);
+    coop_sub(L, Y, V, W, lane, ws);                     // Y3 = R (V - X3) - Y1 HHH
+    coop_mul(L, Z, Z, H, lane, ws);                     // Z3 = Z1 H
 }
 
 // ------------------------------------------------------------------------------------------------
 // Signature::verify for ONE signature by ONE wave (reference src/signature.rs:181-205): the same
 // algorithm as ssa_k_hash + ssa_k_verify (affine table 1P..8P, signed 4-bit windows, comb for G,
 // x-only compare, optional [q]P == O first), every Fp6 operation spread over the wave.
+// LDS slot map: two per-wave working sets (accumulator, addend, nine temporaries, three for inversions)
+// and the slots both waves share (public key, signature x, the 8-entry table with rows X, Y, Z, C).
 namespace coop_slots {
-enum : int { AX = 0, AY, AZ, QX, QY, PX, PY, SX, T0, I0 = T0 + 9, I1, I2, TAB };   // TAB: 8 x (X, Y, Z, C)
+enum : int { WS_SLOTS = 17, PX = 2 * WS_SLOTS, PY, SX, TAB };
 }
+#define COOP_WORKING_SET(ws)                                                                             \
+    const int AX = (ws) * coop_slots::WS_SLOTS, AY = AX + 1, AZ = AX + 2, QX = AX + 3, QY = AX + 4, T0 = AX + 5, \
+              I0 = AX + 14, I1 = AX + 15, I2 = AX + 16;                                                  \
+    (void)AY; (void)AZ; (void)QX; (void)QY; (void)T0; (void)I0; (void)I1; (void)I2
 
 // Rescue-Prime permutation on the 12 lanes 0..11; state in plane L.st[0], L.st[1] is scratch
-COOP_FN void coop_rescue_permutation(CoopLds &L, const DevParams *__restrict__ prm, u32 lane) {
+COOP_FN void coop_rescue_permutation(CoopLds &L, const DevParams *__restrict__ prm, u32 lane, int ws = 0) {
     const u32 nr = prm->n_rounds;
     const bool small = (prm->flags & PRM_FLAG_SMALL_MDS) != 0;
     u64 *S = L.st[0], *T = L.st[1];
@@ -208,7 +227,7 @@ COOP_FN void coop_rescue_permutation(CoopLds &L, const DevParams *__restrict__ p
         for (int half = 0; half < 2; half++) {
             u64 *src = half ? T : S, *dst = half ? S : T;
             if (lane < 12) src[lane] = half ? inv_sbox(src[lane]) : sbox(src[lane]);
-            __syncthreads();
+            coop_sync();
             if (lane < 12) {
                 const u64 *row = prm->mds + lane * 12;
                 const u64 *ark = (half ? prm->ark2 : prm->ark1) + 12 * r;
@@ -221,18 +240,18 @@ COOP_FN void coop_rescue_permutation(CoopLds &L, const DevParams *__restrict__ p
                 }
                 dst[lane] = fp_add(acc_reduce(acc), ark[lane]);
             }
-            __syncthreads();
+            coop_sync();
         }
     }
 }
 
 // hash_message (src/signature.rs:274-306) of the signature staged in slots SX / PX / PY -> scalar h
-COOP_FN sc256 coop_hash_message(CoopLds &L, const DevParams *__restrict__ prm, const u8 *m, u32 len, u32 lane) {
+COOP_FN sc256 coop_hash_message(CoopLds &L, const DevParams *__restrict__ prm, const u8 *m, u32 len, u32 lane, int ws = 0) {
     using namespace coop_slots;
     const u32 nmsg = (len + 6u) / 7u, n_felts = 13u + nmsg;
     u64 *S = L.st[0];
     if (lane < 12) S[lane] = ((int)lane == prm->cap_len_idx) ? (u64)n_felts : 0ull;
-    __syncthreads();
+    coop_sync();
     const u32 rate_off = prm->rate_off;
     const bool pad1 = prm->pad_mode == 1;
     const u32 n_blocks = pad1 ? n_felts / 8 + 1 : (n_felts + 7) / 8;
@@ -254,19 +273,20 @@ COOP_FN sc256 coop_hash_message(CoopLds &L, const DevParams *__restrict__ prm, c
             }
             if (have) S[rate_off + lane] = fp_add(S[rate_off + lane], v);
         }
-        __syncthreads();
-        coop_rescue_permutation(L, prm, lane);
+        coop_sync();
+        coop_rescue_permutation(L, prm, lane, ws);
     }
     sc256 h;
 #pragma unroll
     for (int k = 0; k < 4; k++) h.w[k] = fp_canon(S[prm->digest_off + k]);
-    __syncthreads();
+    coop_sync();
     return sc_reduce256(h);    // Scalar::from_bits_vartime, src/signature.rs:189-192
 }
 
 // affine multiples 1P..8P into the TAB slots (rows of X, Y, Z, C); identity multiples become (0, 0)
-COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane) {
+COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane, int ws = 0) {
     using namespace coop_slots;
+    COOP_WORKING_SET(ws);
     int t[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) t[k] = T0 + k;
@@ -274,151 +294,197 @@ COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane) {
     if (p_inf) {
 #pragma unroll 1
         for (int e = 0; e < 8; e++) {
-            coop_set(L, row(e, 0), 0ull, lane);
-            coop_set(L, row(e, 1), 0ull, lane);
+            coop_set(L, row(e, 0), 0ull, lane, ws);
+            coop_set(L, row(e, 1), 0ull, lane, ws);
         }
         return;
     }
-    coop_copy(L, row(0, 0), PX, lane);
-    coop_copy(L, row(0, 1), PY, lane);
-    coop_set(L, row(0, 2), 1ull, lane);
+    coop_copy(L, row(0, 0), PX, lane, ws);
+    coop_copy(L, row(0, 1), PY, lane, ws);
+    coop_set(L, row(0, 2), 1ull, lane, ws);
     // (source row, operation): 2P = dbl 1P, 3P = 2P + P, 4P = dbl 2P, 5P = 4P + P, 6P = dbl 3P, 7P = 6P + P, 8P = dbl 4P
     const int src[7] = {0, 1, 1, 3, 2, 5, 3};
     const bool is_add[7] = {false, true, false, true, false, true, false};
 #pragma unroll 1
     for (int e = 1; e < 8; e++) {
         const int s = src[e - 1];
-        coop_copy(L, AX, row(s, 0), lane);
-        coop_copy(L, AY, row(s, 1), lane);
-        coop_copy(L, AZ, row(s, 2), lane);
-        if (is_add[e - 1]) coop_jac_madd(L, AX, AY, AZ, PX, PY, t, lane);
-        else coop_jac_dbl(L, AX, AY, AZ, t, lane);
-        coop_copy(L, row(e, 0), AX, lane);
-        coop_copy(L, row(e, 1), AY, lane);
-        coop_copy(L, row(e, 2), AZ, lane);
+        coop_copy(L, AX, row(s, 0), lane, ws);
+        coop_copy(L, AY, row(s, 1), lane, ws);
+        coop_copy(L, AZ, row(s, 2), lane, ws);
+        if (is_add[e - 1]) coop_jac_madd(L, AX, AY, AZ, PX, PY, t, lane, ws);
+        else coop_jac_dbl(L, AX, AY, AZ, t, lane, ws);
+        coop_copy(L, row(e, 0), AX, lane, ws);
+        coop_copy(L, row(e, 1), AY, lane, ws);
+        coop_copy(L, row(e, 2), AZ, lane, ws);
     }
     // Montgomery's trick over the (non-zero) Z's
-    coop_set(L, QX, 1ull, lane);                             // running prefix product
+    coop_set(L, QX, 1ull, lane, ws);                             // running prefix product
 #pragma unroll 1
     for (int e = 1; e < 8; e++) {
-        if (coop_is_zero(L, row(e, 2), lane)) coop_set(L, QY, 1ull, lane);
-        else coop_copy(L, QY, row(e, 2), lane);
-        coop_mul(L, QX, QX, QY, lane);
-        coop_copy(L, row(e, 3), QX, lane);
+        if (coop_is_zero(L, row(e, 2), lane, ws)) coop_set(L, QY, 1ull, lane, ws);
+        else coop_copy(L, QY, row(e, 2), lane, ws);
+        coop_mul(L, QX, QX, QY, lane, ws);
+        coop_copy(L, row(e, 3), QX, lane, ws);
     }
-    coop_inv(L, QX, QX, I0, I1, I2, lane);                   // QX = 1 / prod Z
+    coop_inv(L, QX, QX, I0, I1, I2, lane, ws);                   // QX = 1 / prod Z
 #pragma unroll 1
     for (int e = 7; e >= 1; e--) {
-        const bool zero = coop_is_zero(L, row(e, 2), lane);
-        if (zero) coop_set(L, QY, 1ull, lane);
-        else coop_copy(L, QY, row(e, 2), lane);
-        if (e > 1) coop_mul(L, I0, QX, row(e - 1, 3), lane); // 1 / Z_e
-        else coop_copy(L, I0, QX, lane);
-        coop_mul(L, QX, QX, QY, lane);
-        coop_mul(L, I1, I0, I0, lane);                       // Zinv^2
-        coop_mul(L, row(e, 0), row(e, 0), I1, lane);
-        coop_mul(L, I1, I1, I0, lane);                       // Zinv^3
-        coop_mul(L, row(e, 1), row(e, 1), I1, lane);
+        const bool zero = coop_is_zero(L, row(e, 2), lane, ws);
+        if (zero) coop_set(L, QY, 1ull, lane, ws);
+        else coop_copy(L, QY, row(e, 2), lane, ws);
+        if (e > 1) coop_mul(L, I0, QX, row(e - 1, 3), lane, ws); // 1 / Z_e
+        else coop_copy(L, I0, QX, lane, ws);
+        coop_mul(L, QX, QX, QY, lane, ws);
+        coop_mul(L, I1, I0, I0, lane, ws);                       // Zinv^2
+        coop_mul(L, row(e, 0), row(e, 0), I1, lane, ws);
+        coop_mul(L, I1, I1, I0, lane, ws);                       // Zinv^3
+        coop_mul(L, row(e, 1), row(e, 1), I1, lane, ws);
         if (zero) {
-            coop_set(L, row(e, 0), 0ull, lane);
-            coop_set(L, row(e, 1), 0ull, lane);
+            coop_set(L, row(e, 0), 0ull, lane, ws);
+            coop_set(L, row(e, 1), 0ull, lane, ws);
         }
     }
 }
 
 // (AX, AY, AZ) <- [k] P from the table, k < 2^255
-COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane) {
+COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane, int ws = 0) {
     using namespace coop_slots;
+    COOP_WORKING_SET(ws);
     int t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) t[i] = T0 + i;
     const sc256 kr = sc_recode_offset(k);
-    coop_set(L, AX, 1ull, lane);
-    coop_set(L, AY, 1ull, lane);
-    coop_set(L, AZ, 0ull, lane);
+    coop_set(L, AX, 1ull, lane, ws);
+    coop_set(L, AY, 1ull, lane, ws);
+    coop_set(L, AZ, 0ull, lane, ws);
     const u32 top = sc_nibble(kr, 63u);
     if (top != 0) {
         const int e = (int)top - 1;
-        if (!(coop_is_zero(L, TAB + 4 * e, lane) && coop_is_zero(L, TAB + 4 * e + 1, lane))) {
-            coop_copy(L, AX, TAB + 4 * e, lane);
-            coop_copy(L, AY, TAB + 4 * e + 1, lane);
-            coop_set(L, AZ, 1ull, lane);
+        if (!(coop_is_zero(L, TAB + 4 * e, lane, ws) && coop_is_zero(L, TAB + 4 * e + 1, lane, ws))) {
+            coop_copy(L, AX, TAB + 4 * e, lane, ws);
+            coop_copy(L, AY, TAB + 4 * e + 1, lane, ws);
+            coop_set(L, AZ, 1ull, lane, ws);
         }
     }
 #pragma unroll 1
     for (int w = 62; w >= 0; w--) {
 #pragma unroll 1
-        for (int d = 0; d < 4; d++) coop_jac_dbl(L, AX, AY, AZ, t, lane);
+        for (int d = 0; d < 4; d++) coop_jac_dbl(L, AX, AY, AZ, t, lane, ws);
         const int digit = (int)sc_nibble(kr, (u32)w) - 8;
         if (digit != 0) {
             const int e = (digit < 0 ? -digit : digit) - 1;
-            coop_copy(L, QX, TAB + 4 * e, lane);
-            if (digit < 0) coop_neg(L, QY, TAB + 4 * e + 1, lane);
-            else coop_copy(L, QY, TAB + 4 * e + 1, lane);
-            coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane);
+            coop_copy(L, QX, TAB + 4 * e, lane, ws);
+            if (digit < 0) coop_neg(L, QY, TAB + 4 * e + 1, lane, ws);
+            else coop_copy(L, QY, TAB + 4 * e + 1, lane, ws);
+            coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane, ws);
         }
     }
 }
 
-COOP_FN u32 coop_verify_one(CoopLds &L, const DevParams *__restrict__ prm, const u8 *__restrict__ sig,
-                            const u8 *__restrict__ pk, bool inf, const u8 *__restrict__ m, u32 len,
-                            const u64 *__restrict__ gtab, u32 flags, u32 lane) {
+// Two waves per signature (a 128-thread block).  After the inputs are staged:
+//   wave 0: key checks + table build        ||  wave 1: hash_message -> h
+//   wave 0: [q]P == O (with the flag)       ||  wave 1: [h]P + [e]G and the x comparison
+// The waves share the table and the staged inputs, keep separate working sets, and meet at three
+// workgroup barriers.  Check order as in the reference (src/signature.rs:181-205): key decoding,
+// subgroup check (InvalidPublicKey), then the signature's x (the reference panics: SSA_MALFORMED).
+struct CoopShared {
+    u32 ok_pk, ok_sig, tors_bad, eq;
+    u64 h[4];
+};
+
+COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *__restrict__ prm,
+                                  const u8 *__restrict__ sig, const u8 *__restrict__ pk, bool inf,
+                                  const u8 *__restrict__ m, u32 len, const u64 *__restrict__ gtab, u32 flags,
+                                  u32 lane, int ws) {
     using namespace coop_slots;
+    COOP_WORKING_SET(ws);
     int t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) t[i] = T0 + i;
-    // stage and validate the inputs
-    bool ok_lane = true;
-    if (lane < 6) {
-        const u64 xs = ld_u64_le(sig + 8 * lane), px = ld_u64_le(pk + 8 * lane), py = ld_u64_le(pk + 48 + 8 * lane);
-        L.slot[SX][lane] = xs;
-        L.slot[PX][lane] = px;
-        L.slot[PY][lane] = py;
-        ok_lane = xs < FP_P && px < FP_P && py < FP_P;
-    }
     const sc256 e = ld_sc(sig + 49);
-    bool ok = __all(ok_lane) && !sc_geq_q(e);
-    __syncthreads();
-    if (ok && !inf) {   // y^2 == x^3 + x + (u + 395)
-        coop_mul(L, T0, PX, PX, lane);
-        coop_mul(L, T0, T0, PX, lane);
-        coop_add(L, T0, T0, PX, lane);
-        if (lane < 2) L.slot[T0][lane] = fp_add(L.slot[T0][lane], lane == 0 ? 395ull : 1ull);
-        __syncthreads();
-        coop_mul(L, T0 + 1, PY, PY, lane);
-        ok = coop_eq(L, T0, T0 + 1, lane);
-    }
-    if (!ok) return ST_MALFORMED;
-    const sc256 h = coop_hash_message(L, prm, m, len, lane);
-    coop_build_table(L, inf, lane);
-    if (flags & 1u) {   // is_torsion_free, src/signature.rs:182-184
-        sc256 q;
-#pragma unroll
-        for (int k = 0; k < 4; k++) q.w[k] = SC_Q(k);
-        coop_mul_table(L, q, lane);
-        if (!coop_is_zero(L, AZ, lane)) return ST_INVALID_PK;
-    }
-    coop_mul_table(L, h, lane);                                   // [h]P
-#pragma unroll 1
-    for (int w = 0; w < 16; w++) {                                // + [e]G, src/signature.rs:196-198
-        const u32 d = sc_win16(e, (u32)w);
-        if (d != 0) {
-            const u64 *rowp = gtab + (((size_t)w << 16) + d) * 12;
-            if (lane < 6) L.slot[QX][lane] = rowp[lane];
-            else if (lane < 12) L.slot[QY][lane - 6] = rowp[lane];
-            __syncthreads();
-            coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane);
+    if (ws == 0) {   // stage the inputs, canonical-limb checks
+        bool pk_ok = true, sig_ok = true;
+        if (lane < 6) {
+            const u64 xs = ld_u64_le(sig + 8 * lane), px = ld_u64_le(pk + 8 * lane), py = ld_u64_le(pk + 48 + 8 * lane);
+            L.slot[SX][lane] = xs;
+            L.slot[PX][lane] = px;
+            L.slot[PY][lane] = py;
+            pk_ok = px < FP_P && py < FP_P;
+            sig_ok = xs < FP_P;
+        }
+        pk_ok = __all(pk_ok);
+        sig_ok = __all(sig_ok) && !sc_geq_q(e);
+        if (lane == 0) {
+            sh.ok_pk = pk_ok;
+            sh.ok_sig = sig_ok;
+            sh.tors_bad = 0;
+            sh.eq = 0;
         }
     }
-    bool eq;
-    if (coop_is_zero(L, AZ, lane)) {
-        eq = coop_is_zero(L, SX, lane);                           // the identity's x is taken as 0
+    __syncthreads();
+    if (ws == 0) {
+        bool ok = sh.ok_pk != 0;
+        if (ok && !inf) {   // y^2 == x^3 + x + (u + 395)
+            coop_mul(L, T0, PX, PX, lane, ws);
+            coop_mul(L, T0, T0, PX, lane, ws);
+            coop_add(L, T0, T0, PX, lane, ws);
+            if (lane < 2) L.slot[T0][lane] = fp_add(L.slot[T0][lane], lane == 0 ? 395ull : 1ull);
+            coop_sync();
+            coop_mul(L, T0 + 1, PY, PY, lane, ws);
+            ok = coop_eq(L, T0, T0 + 1, lane, ws);
+        }
+        if (lane == 0) sh.ok_pk = ok;
+        if (ok) coop_build_table(L, inf, lane, ws);
     } else {
-        coop_mul(L, T0, AZ, AZ, lane);
-        coop_mul(L, T0, SX, T0, lane);
-        eq = coop_eq(L, AX, T0, lane);                            // X == x * Z^2, src/signature.rs:200
+        const sc256 h = coop_hash_message(L, prm, m, len, lane, ws);   // reads SX, PX, PY only
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sh.h[k] = h.w[k];
+        }
     }
-    return eq ? ST_OK : ST_INVALID_SIG;
+    __syncthreads();
+    if (sh.ok_pk) {
+        if (ws == 0) {
+            if (flags & 1u) {   // is_torsion_free, src/signature.rs:182-184
+                sc256 q;
+#pragma unroll
+                for (int k = 0; k < 4; k++) q.w[k] = SC_Q(k);
+                coop_mul_table(L, q, lane, ws);
+                const bool at_identity = coop_is_zero(L, AZ, lane, ws);
+                if (lane == 0) sh.tors_bad = at_identity ? 0u : 1u;
+            }
+        } else if (sh.ok_sig) {
+            sc256 h;
+#pragma unroll
+            for (int k = 0; k < 4; k++) h.w[k] = sh.h[k];
+            coop_mul_table(L, h, lane, ws);                               // [h]P
+#pragma unroll 1
+            for (int w = 0; w < 16; w++) {                                // + [e]G, src/signature.rs:196-198
+                const u32 d = sc_win16(e, (u32)w);
+                if (d != 0) {
+                    const u64 *rowp = gtab + (((size_t)w << 16) + d) * 12;
+                    if (lane < 6) L.slot[QX][lane] = rowp[lane];
+                    else if (lane < 12) L.slot[QY][lane - 6] = rowp[lane];
+                    coop_sync();
+                    coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane, ws);
+                }
+            }
+            bool eq;
+            if (coop_is_zero(L, AZ, lane, ws)) {
+                eq = coop_is_zero(L, SX, lane, ws);                       // the identity's x is taken as 0
+            } else {
+                coop_mul(L, T0, AZ, AZ, lane, ws);
+                coop_mul(L, T0, SX, T0, lane, ws);
+                eq = coop_eq(L, AX, T0, lane, ws);                        // X == x * Z^2, src/signature.rs:200
+            }
+            if (lane == 0) sh.eq = eq;
+        }
+    }
+    __syncthreads();
+    if (!sh.ok_pk) return ST_MALFORMED;
+    if ((flags & 1u) && sh.tors_bad) return ST_INVALID_PK;
+    if (!sh.ok_sig) return ST_MALFORMED;
+    return sh.eq ? ST_OK : ST_INVALID_SIG;
 }
 
 }  // namespace ssa

@@ -327,10 +327,12 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32 status = ST_OK;
     if (i < n) {
-        bool ok = true;
-        const fp6 xs = ld_fp6(sigs + 81 * i, ok);           // Fp6::from_bytes(..).unwrap(), :186
+        // check order of the reference (src/signature.rs:181-205): the key first (subgroup check, :182),
+        // then the signature's x (Fp6::from_bytes(..).unwrap() panics at :186 -> SSA_MALFORMED)
+        bool ok_sig = true, ok = true;
+        const fp6 xs = ld_fp6(sigs + 81 * i, ok_sig);
         const sc256 e = ld_sc(sigs + 81 * i + 49);
-        ok = ok && !sc_geq_q(e);
+        ok_sig = ok_sig && !sc_geq_q(e);
         aff P;
         P.x = ld_fp6(pks + 96 * i, ok);
         P.y = ld_fp6(pks + 96 * i + 48, ok);
@@ -349,6 +351,10 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
             jac r = jac_identity();
 #pragma unroll 1
             for (int pass = (flags & 1u) ? 0 : 1; pass < 2; pass++) {
+                if (pass == 1 && !ok_sig) {
+                    status = ST_MALFORMED;
+                    break;
+                }
                 sc256 k = h;
                 if (pass == 0) {
 #pragma unroll
@@ -716,18 +722,19 @@ __global__ void __launch_bounds__(256) ssa_k_f6mul_bench(u64 *out, u64 seed, int
 
 #ifndef SSA_NO_KERNELS
 namespace ssa {
-// Low-latency verification: one wave (one 64-thread block) per signature.
-__global__ void __launch_bounds__(64)
+// Low-latency verification: two cooperating waves (one 128-thread block) per signature.
+__global__ void __launch_bounds__(128)
 ssa_k_verify_coop(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
                   const u8 *__restrict__ pk_inf, MsgView mv, const u64 *__restrict__ gtab, size_t n, u32 flags,
                   u8 *__restrict__ status_out, unsigned long long *__restrict__ n_fail) {
     __shared__ CoopLds L;
+    __shared__ CoopShared sh;
     const size_t i = blockIdx.x;
     if (i >= n) return;
     u32 len;
     const u8 *m = msg_ptr(mv, i, len);
-    const u32 st = coop_verify_one(L, prm, sigs + 81 * i, pks + 96 * i, pk_inf && pk_inf[i], m, len, gtab, flags,
-                                   threadIdx.x);
+    const u32 st = coop_verify_two_waves(L, sh, prm, sigs + 81 * i, pks + 96 * i, pk_inf && pk_inf[i], m, len, gtab,
+                                         flags, threadIdx.x & 63u, (int)(threadIdx.x >> 6));
     if (threadIdx.x == 0) {
         status_out[i] = (u8)st;
         if (st != ST_OK) atomicAdd(n_fail, 1ull);

@@ -220,7 +220,7 @@ msm_k_shift(const u64 *__restrict__ win_in, MsmShape sh, u64 *__restrict__ win_o
 #pragma unroll
     for (int k = 0; k < 9; k++) t[k] = 3 + k;
     if (lane < 18) L.slot[lane / 6][lane % 6] = win_in[18 * (size_t)j + lane];
-    __syncthreads();
+    coop_sync();
 #pragma unroll 1
     for (u32 s = 0; s < j * sh.c; s++) coop_jac_dbl(L, 0, 1, 2, t, lane);
     if (lane < 18) win_out[18 * (size_t)j + lane] = L.slot[lane / 6][lane % 6];
