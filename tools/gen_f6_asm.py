@@ -1,0 +1,233 @@
+"""Generates schnorr-sig_amd/csrc/fp6_asm.inc: the lazy Fp6 product and square as ONE inline-asm block each.
+
+The multiply-accumulate chains and the six final reductions need two views of the accumulator columns
+-- 64-bit register pairs for v_mad_u64_u32, 32-bit halves for the carry chains of the reduction -- and
+inline-asm operands cannot name half of a pair.  The accumulators therefore live in fixed VGPRs that
+the block declares as clobbers; they are all caller-saved registers of the amdgpu calling convention
+above the argument registers and below v128 (v48-55, v64-71, v80-87, v96-103; v0-v39 stay free for the
+arguments and the pre-scaled operands the compiler computes), so the
+out-of-line f6_mul_flat / f6_sqr_flat that contain the block need no saves and no argument moves.
+Carries use vcc and s[0:11] (caller-saved, declared as clobbers).
+
+gfx950 needs two wait states between a VALU write of a carry (vcc / SGPR pair) and the VALU read of it;
+the compiler pads its own code with s_nop but nothing inside an asm string is padded.  Every pattern
+below keeps at least two other instructions between a carry's producer and its consumer:
+  * multiply-accumulate (4 mads + 4 carry adds) and the two-product chain opener: the independent mads
+    of the same product sit between producer and consumer;
+  * the reductions are issued three at a time, round-robin, one step of each chain at a time (two
+    instructions between dependent steps); three accumulators = 27 registers are live at once, which
+    keeps the whole block below v128 (a non-kernel function may not use v128 and above).
+
+Reduction of one accumulator (value = c0 + 2^32 c1 + 2^64 (c2 + k0) + 2^96 k1 + 2^128 k2):
+  2^64 = EPS = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p)
+  m  = c0h + c1l                (carry cL, weight 2^64)
+  sl = c1h + c2l + k0 + cL      (its carries ca, cb weigh 2^96 = -1: folded into t0)
+  t0 = c2h + k1 + ca + cb,  th = k2 + carries of t0
+  r  = (c0l, m) - (t0, th) [borrow: - EPS] + EPS * sl [carry: + EPS]        -- as fp_reduce_parts
+"""
+import os
+
+# caller-saved VGPRs above the argument registers and below v128 (a non-kernel function may not touch
+# v128+), as even-aligned pairs.  Three accumulators (27 registers) are live at a time; the first
+# group's six result words wait in RES until the end.
+POOL = []
+for lo, hi in ((48, 55), (64, 71), (80, 87), (96, 103), (112, 119)):
+    POOL += list(range(lo, hi + 1))
+PAIRS = [(POOL[i], POOL[i + 1]) for i in range(0, len(POOL), 2)]
+assert all(p[0] % 2 == 0 and p[1] == p[0] + 1 for p in PAIRS)
+N_FIXED = 9 * 2 + 9 + 6          # 9 column pairs, 9 counters, 6 parked result words
+RES = POOL[27:33]
+
+
+class Acc:
+    def __init__(self, j):
+        j %= 3
+        self.c = PAIRS[j * 3:(j * 3) + 3]        # three column pairs
+        flat = POOL[18:27]                       # the nine counters
+        self.k = flat[j * 3:j * 3 + 3]
+
+    def pair(self, i):
+        return "v[%d:%d]" % self.c[i]
+
+    def lo(self, i):
+        return "v%d" % self.c[i][0]
+
+    def hi(self, i):
+        return "v%d" % self.c[i][1]
+
+    def kk(self, i):
+        return "v%d" % self.k[i]
+
+
+S0, S1 = "s[0:1]", "s[2:3]"
+
+
+def init2(acc, x, y, z, w):
+    """acc = x*y + z*w; operands are names of u64 inputs (halves %[<name>l] / %[<name>h])."""
+    xl, xh, yl, yh = "%%[%sl]" % x, "%%[%sh]" % x, "%%[%sl]" % y, "%%[%sh]" % y
+    zl, zh, wl, wh = "%%[%sl]" % z, "%%[%sh]" % z, "%%[%sl]" % w, "%%[%sh]" % w
+    c0, c1, c2 = acc.pair(0), acc.pair(1), acc.pair(2)
+    k0, k1, k2 = acc.kk(0), acc.kk(1), acc.kk(2)
+    return [
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (c0, S0, xl, yl),
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (c1, S0, xl, yh),
+        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (c2, S0, xh, yh),
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (c1, xh, yl, c1),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c0, S0, zl, wl, c0),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c1, S1, zl, wh, c1),
+        "v_addc_co_u32 %s, vcc, 0, 0, vcc" % k1,
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (c1, zh, wl, c1),
+        "v_addc_co_u32 %s, %s, 0, 0, %s" % (k0, S0, S0),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c2, S0, zh, wh, c2),
+        "v_addc_co_u32 %s, %s, 0, %s, %s" % (k1, S1, k1, S1),
+        "v_addc_co_u32 %s, vcc, 0, %s, vcc" % (k1, k1),
+        "v_addc_co_u32 %s, %s, 0, 0, %s" % (k2, S0, S0),
+    ]
+
+
+def mac(acc, x, y):
+    xl, xh, yl, yh = "%%[%sl]" % x, "%%[%sh]" % x, "%%[%sl]" % y, "%%[%sh]" % y
+    c0, c1, c2 = acc.pair(0), acc.pair(1), acc.pair(2)
+    k0, k1, k2 = acc.kk(0), acc.kk(1), acc.kk(2)
+    return [
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c0, S0, xl, yl, c0),
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (c1, xl, yh, c1),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c2, S1, xh, yh, c2),
+        "v_addc_co_u32 %s, vcc, 0, %s, vcc" % (k1, k1),
+        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (c1, xh, yl, c1),
+        "v_addc_co_u32 %s, %s, 0, %s, %s" % (k0, S0, k0, S0),
+        "v_addc_co_u32 %s, %s, 0, %s, %s" % (k2, S1, k2, S1),
+        "v_addc_co_u32 %s, vcc, 0, %s, vcc" % (k1, k1),
+    ]
+
+
+REDUCE_STEPS = [
+    "v_add_co_u32 {c0h}, {A}, {c0h}, {c1l}",          # 1  m
+    "v_addc_co_u32 {c1h}, {A}, {c1h}, {c2l}, {A}",    # 2  sa
+    "v_add_co_u32 {c1h}, {B}, {c1h}, {k0}",           # 3  sl
+    "v_addc_co_u32 {c2h}, {A}, {c2h}, {k1}, {A}",     # 4  t0 = c2h + k1 + ca
+    "v_addc_co_u32 {c2h}, {B}, 0, {c2h}, {B}",        # 5  t0 += cb
+    "v_addc_co_u32 {k2}, {A}, 0, {k2}, {A}",          # 6  th = k2 + carry(4)
+    "v_addc_co_u32 {k2}, {B}, 0, {k2}, {B}",          # 7  th += carry(5)
+    "v_sub_co_u32 {c1l}, {A}, 0, {c1h}",              # 8  M0 = -sl
+    "v_sub_co_u32 {c0l}, {B}, {c0l}, {c2h}",          # 9  r0 = c0l - t0
+    "v_subbrev_co_u32 {c2l}, {A}, 0, {c1h}, {A}",     # 10 M1 = sl - borrow(8)
+    "v_subb_co_u32 {c0h}, {B}, {c0h}, {k2}, {B}",     # 11 r1 = m - th - borrow(9)
+    "v_cndmask_b32_e64 {k0}, 0, -1, {B}",             # 12 e = borrow ? EPS : 0
+    "v_sub_co_u32 {c0l}, {B}, {c0l}, {k0}",           # 13 r -= e
+    "v_subbrev_co_u32 {c0h}, {B}, 0, {c0h}, {B}",     # 14
+    "v_add_co_u32 {c0l}, {A}, {c0l}, {c1l}",          # 15 r += M
+    "v_addc_co_u32 {c0h}, {A}, {c0h}, {c2l}, {A}",    # 16
+    "v_cndmask_b32_e64 {k0}, 0, -1, {A}",             # 17 e = carry ? EPS : 0
+    "v_add_co_u32 {outl}, {A}, {c0l}, {k0}",          # 18 r += e, straight into the output operand
+    "v_addc_co_u32 {outh}, {A}, 0, {c0h}, {A}",       # 19
+]
+
+
+def reduce3(accs, outs):
+    """outs[j] = (lo, hi) destination of chain j's result"""
+    lines = []
+    for step in REDUCE_STEPS:
+        for j, a in enumerate(accs):
+            m = {"c0l": a.lo(0), "c0h": a.hi(0), "c1l": a.lo(1), "c1h": a.hi(1), "c2l": a.lo(2), "c2h": a.hi(2),
+                 "k0": a.kk(0), "k1": a.kk(1), "k2": a.kk(2), "A": "s[%d:%d]" % (4 * j, 4 * j + 1),
+                 "B": "s[%d:%d]" % (4 * j + 2, 4 * j + 3), "outl": outs[j][0], "outh": outs[j][1]}
+            lines.append(step.format(**m))
+    return lines
+
+
+def mul_terms():
+    """c_k = sum_{i<=k} a_i b_{k-i} + sum_{i>k} a_i (7 b_{k+6-i})"""
+    out = []
+    for k in range(6):
+        t = []
+        for i in range(6):
+            t.append(("a%d" % i, "b%d" % (k - i)) if i <= k else ("a%d" % i, "s%d" % (k + 6 - i)))
+        out.append(t)
+    return out
+
+
+def sqr_terms():
+    """direct i + j = k (i <= j): a_i * (a_j | 2a_j); wrapped i + j = k + 6: a_i * (7a_j | 14a_j)"""
+    out = []
+    for k in range(6):
+        t = []
+        for i in range(0, k // 2 + 1):
+            j = k - i
+            t.append(("a%d" % i, ("a%d" if i == j else "d%d") % j))
+        for i in range(k + 1, (k + 6) // 2 + 1):
+            j = k + 6 - i
+            if j > 5:
+                continue
+            t.append(("a%d" % i, ("s%d" if i == j else "t%d") % j))
+        out.append(t)
+    return out
+
+
+def emit(name, terms, inputs, doc):
+    accs = [Acc(j) for j in range(6)]
+    lines = []
+    for g in range(2):
+        for k in range(3 * g, 3 * g + 3):
+            t = terms[k]
+            assert len(t) >= 2
+            lines += init2(accs[k], t[0][0], t[0][1], t[1][0], t[1][1])
+            for x, y in t[2:]:
+                lines += mac(accs[k], x, y)
+        if g == 0:   # inputs are still needed: park the results in fixed registers
+            outs = [("v%d" % RES[2 * j], "v%d" % RES[2 * j + 1]) for j in range(3)]
+        else:
+            outs = [("%%[r%dl]" % k, "%%[r%dh]" % k) for k in range(3, 6)]
+        lines += reduce3(accs[3 * g:3 * g + 3], outs)
+    for j in range(3):
+        lines.append("v_mov_b32 %%[r%dl], v%d" % (j, RES[2 * j]))
+        lines.append("v_mov_b32 %%[r%dh], v%d" % (j, RES[2 * j + 1]))
+    used = set()
+    for ln in lines:
+        for tok in ln.replace(",", " ").split():
+            if tok.startswith("%["):
+                used.add(tok[2:-1])
+    out = ["// %s" % doc, "SSA_DEV void %s(%s, u64 (&r)[6]) {" % (name, ", ".join("const u64 (&%s)[6]" % n for n, _ in inputs))]
+    out.append("    u32 " + ", ".join("r%dl, r%dh" % (j, j) for j in range(6)) + ";")
+    out.append("    asm(")
+    for i, ln in enumerate(lines):
+        out.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(lines) else ""))
+    outs = []
+    for j in range(6):
+        outs.append('[r%dl] "=v"(r%dl)' % (j, j))
+        outs.append('[r%dh] "=v"(r%dh)' % (j, j))
+    out.append("        : " + ", ".join(outs))
+    ins = []
+    for arr, prefix in inputs:
+        for j in range(6):
+            nm = "%s%d" % (prefix, j)
+            if nm + "l" in used or nm + "h" in used:
+                ins.append('[%sl] "v"(lo32(%s[%d]))' % (nm, arr, j))
+                ins.append('[%sh] "v"(hi32(%s[%d]))' % (nm, arr, j))
+    out.append("        : " + ",\n          ".join(ins))
+    clob = ['"v%d"' % r for r in POOL[:N_FIXED]] + ['"s%d"' % i for i in range(12)] + ['"vcc"']
+    out.append("        : " + ", ".join(clob) + ");")
+    for j in range(6):
+        out.append("    r[%d] = mk64(r%dl, r%dh);" % (j, j, j))
+    out.append("}")
+    nm = sum(1 for ln in lines if ln.startswith("v_mad"))
+    return out, len(lines), nm
+
+
+def main():
+    hdr = ["// generated by tools/gen_f6_asm.py -- do not edit (see that file for the design notes)"]
+    m, nl, nm = emit("f6_mul_core_asm", mul_terms(), [("a", "a"), ("b", "b"), ("b7", "s")],
+                     "r = a * b in Fp[u]/(u^6 - 7); b7[j] = 7 b[j] (j = 1..5)")
+    print("mul: %d instructions, %d mads" % (nl, nm))
+    s, nl, nm = emit("f6_sqr_core_asm", sqr_terms(), [("a", "a"), ("a2", "d"), ("a7", "s"), ("a14", "t")],
+                     "r = a^2; a2[j] = 2 a[j] (j = 1..5), a7[j] = 7 a[j], a14[j] = 14 a[j] (j = 3..5)")
+    print("sqr: %d instructions, %d mads" % (nl, nm))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc",
+                        "fp6_asm.inc")
+    with open(path, "w") as fh:
+        fh.write("\n".join(hdr + m + [""] + s) + "\n")
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
