@@ -61,7 +61,8 @@ SSA_DEV bool fp_is_zero(u64 a) { return a == 0ull || a == FP_P; }
 SSA_DEV bool fp_eq(u64 a, u64 b) { return fp_canon(a) == fp_canon(b); }
 
 // (2^32 - 1) * h as a 64-bit value.  hipcc emits one v_mad_u64_u32 by 0xffffffff for this; a
-// hand-written v_sub_co/v_subbrev pair measured 8 % slower in the Fp-mul probe (VCC dependency).
+// hand-written v_sub_co/v_subbrev pair measured 8 % slower in the Fp-mul probe (VCC dependency), and the
+// carry-free form (0 - h, h - min(h, 1)) 13 % slower (ssa_k_hash 14.6 -> 16.5 ms).
 SSA_DEV u64 eps_times(u32 h) { return ((u64)h << 32) - h; }
 
 // Reduce lo + 2^64*(h0 + 2^32*h1), h1 < 2^64 allowed as a full 64-bit "top" value:

@@ -1,9 +1,10 @@
 // Wave-cooperative arithmetic: ONE WAVE works on ONE point / ONE signature.
 //
 // The per-lane kernels (ssa_kernels.cuh) need ~65 k lanes to fill the chip and take ~8 ms per call
-// however small the batch is, because a lane runs its ~330 point operations serially.  Here the 36
-// products of an Fp6 multiplication go to 36 lanes, six lanes add up the columns and reduce, operands
-// live in LDS.  Used for (1) the sequential tail of the MSM reduction (ssa_msm.hip) and (2) the
+// however small the batch is, because a lane runs its ~330 point operations serially.  Here a wave
+// shares the work of one point operation: Fp6 values live in LDS slots, independent products of a formula
+// run side by side (six lanes per product, one LDS round trip per round), a lone product is spread over 36
+// lanes, and the additions between the products are folded into a few linear steps.  Used for (1) the sequential tail of the MSM reduction (ssa_msm.hip) and (2) the
 // low-latency verification kernel ssa_k_verify_coop (small batches, single Signature::verify calls).
 //
 // Every function here must be called by ALL 64 threads of a one-wave block (blockDim.x == 64);
@@ -15,16 +16,20 @@ namespace ssa {
 
 constexpr int COOP_SLOTS = 72;
 
+// A slot holds an Fp6 value v (words 0..5) and 7*v (words 6..11): the product rounds read the wrapped
+// terms (u^6 = 7) of their second operand from the upper half, so nobody scales on the critical path.
+// Every primitive below keeps the upper half valid; code that stores into a slot by hand must do the same
+// (coop_store7).
 struct CoopLds {
-    u64 slot[COOP_SLOTS][6];  // Fp6 values
-    u64 part[2][6][6][3];     // per cooperating wave: products (x7 where wrapped) grouped by output coefficient
+    u64 slot[COOP_SLOTS][12];
+    u64 part[2][6][6][3];     // coop_mul: per cooperating wave, products grouped by output coefficient
     u64 st[2][12];            // Rescue state planes
 };
 
 #define COOP_FN __device__ __forceinline__
 
-// Ordering point between LDS writes and reads of different lanes.  The blocks that run this code are
-// ONE wave, so no s_barrier is needed: LDS executes a wave's instructions in order; the fence keeps the
+// Ordering point between LDS writes and reads of different lanes.  The code here runs on ONE wave per
+// working set, so no s_barrier is needed: LDS executes a wave's instructions in order; the fence keeps the
 // compiler from moving accesses across it and waits for outstanding LDS operations.
 COOP_FN void coop_sync() {
 #ifdef SSA_COOP_USE_BARRIER
@@ -36,29 +41,29 @@ COOP_FN void coop_sync() {
 #endif
 }
 
+// lanes 0..11 store v (lanes 0..5: coefficient `lane`) and 7 v (lanes 6..11) of a value given per coefficient
+COOP_FN void coop_store7(CoopLds &L, int dst, u64 coef, u32 lane) {
+    if (lane < 12) L.slot[dst][lane] = lane < 6 ? coef : fp_mul_small(coef, 7u);
+}
+
+// One product on 36 lanes (one 64x64 product each), six lanes add up the columns and reduce: the lowest
+// latency for a lone product (two LDS round trips).
 COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
-    // 36 lanes: one 64x64 product each; wrapped terms (u^6 = 7) are scaled by 7 in the same lane
     if (lane < 36) {
         const u32 i = lane / 6, j = lane % 6;
         u32 k = i + j;
         u64 lo, hi;
-        mul64x64(L.slot[a][i], L.slot[b][j], lo, hi);
-        u64 top = 0;
         if (k >= 6) {
             k -= 6;
-            u64 l7lo, l7hi, h7lo, h7hi;
-            mul64x64(lo, 7ull, l7lo, l7hi);
-            mul64x64(hi, 7ull, h7lo, h7hi);
-            lo = l7lo;
-            hi = h7lo + l7hi;
-            top = h7hi + (hi < l7hi);
+            mul64x64(L.slot[a][i], L.slot[b][6 + j], lo, hi);
+        } else {
+            mul64x64(L.slot[a][i], L.slot[b][j], lo, hi);
         }
         L.part[ws][k][i][0] = lo;
         L.part[ws][k][i][1] = hi;
-        L.part[ws][k][i][2] = top;
     }
     coop_sync();
-    // 6 lanes: column sums (up to 6 * 7 * 2^128 < 2^134) and one Goldilocks reduction each
+    // 6 lanes: column sums (6 * 2^128 < 2^131) and one Goldilocks reduction each
     if (lane < 6) {
         u64 lo = 0, hi = 0, top = 0;
 #pragma unroll
@@ -72,34 +77,76 @@ COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
             const u64 c2 = nh2 < c0;
             lo = nlo;
             hi = nh2;
-            top += c1 + c2 + L.part[ws][lane][t][2];
+            top += c1 + c2;
         }
-        L.slot[dst][lane] = fp_reduce_parts(lo, lo32(hi), (u64)hi32(hi) + (top << 32));
+        const u64 r = fp_reduce_parts(lo, lo32(hi), (u64)hi32(hi) + (top << 32));
+        L.slot[dst][lane] = r;
+        L.slot[dst][6 + lane] = fp_mul_small(r, 7u);
     }
     coop_sync();
 }
+
+// N independent products in ONE LDS round trip: six lanes per product, lane k of a group accumulates the
+// six terms of output coefficient k lazily (the arithmetic of the per-lane kernels) and reduces once.
+// dst may alias a source: every lane reads before any lane writes (one wave, in-order LDS).
+template <int N>
+COOP_FN void coop_mul_round(CoopLds &L, const int (&dst)[N], const int (&a)[N], const int (&b)[N], u32 lane) {
+    static_assert(N >= 1 && N <= 10, "six lanes per product");
+    const u32 g = lane / 6u, k = lane - 6u * g;
+    if (g < (u32)N) {
+        int sa = a[0], sb = b[0], sd = dst[0];
+#pragma unroll
+        for (int n = 1; n < N; n++) {
+            if (g == (u32)n) {
+                sa = a[n];
+                sb = b[n];
+                sd = dst[n];
+            }
+        }
+        const u64 *A = L.slot[sa], *B = L.slot[sb];
+        u64 x[6], y[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            int idx = (int)k - i;          // b_{k-i}, or 7 b_{k-i+6} from the upper half
+            if (idx < 0) idx += 12;
+            x[i] = A[i];
+            y[i] = B[idx];
+        }
+        fp_acc acc;
+        acc_init(acc, x[0], y[0]);
+#pragma unroll
+        for (int i = 1; i < 6; i++) acc_mac(acc, x[i], y[i]);
+        const u64 r = acc_reduce(acc);
+        u64 *D = L.slot[sd];
+        D[k] = r;
+        D[6 + k] = fp_mul_small(r, 7u);
+    }
+    coop_sync();
+}
+
+// linear steps: the same operation on both halves of a slot (7 (a + b) = 7a + 7b)
 COOP_FN void coop_add(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
-    if (lane < 6) L.slot[dst][lane] = fp_add(L.slot[a][lane], L.slot[b][lane]);
+    if (lane < 12) L.slot[dst][lane] = fp_add(L.slot[a][lane], L.slot[b][lane]);
     coop_sync();
 }
 COOP_FN void coop_sub(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
-    if (lane < 6) L.slot[dst][lane] = fp_sub(L.slot[a][lane], L.slot[b][lane]);
+    if (lane < 12) L.slot[dst][lane] = fp_sub(L.slot[a][lane], L.slot[b][lane]);
     coop_sync();
 }
 COOP_FN void coop_neg(CoopLds &L, int dst, int a, u32 lane, int ws = 0) {
-    if (lane < 6) L.slot[dst][lane] = fp_neg(L.slot[a][lane]);
+    if (lane < 12) L.slot[dst][lane] = fp_neg(L.slot[a][lane]);
     coop_sync();
 }
 COOP_FN void coop_copy(CoopLds &L, int dst, int a, u32 lane, int ws = 0) {
-    if (lane < 6) L.slot[dst][lane] = L.slot[a][lane];
+    if (lane < 12) L.slot[dst][lane] = L.slot[a][lane];
     coop_sync();
 }
 COOP_FN void coop_set(CoopLds &L, int dst, u64 c0, u32 lane, int ws = 0) {  // dst = c0 (element of Fp)
-    if (lane < 6) L.slot[dst][lane] = lane == 0 ? c0 : 0ull;
+    if (lane < 12) L.slot[dst][lane] = lane == 0 ? c0 : (lane == 6 ? fp_mul_small(c0, 7u) : 0ull);
     coop_sync();
 }
 COOP_FN void coop_mul_fp(CoopLds &L, int dst, int a, u64 s, u32 lane, int ws = 0) {
-    if (lane < 6) L.slot[dst][lane] = fp_mul(L.slot[a][lane], s);
+    if (lane < 12) L.slot[dst][lane] = fp_mul(L.slot[a][lane], s);
     coop_sync();
 }
 COOP_FN bool coop_is_zero(CoopLds &L, int a, u32 lane, int ws = 0) {
@@ -114,15 +161,16 @@ COOP_FN bool coop_eq(CoopLds &L, int a, int b, u32 lane, int ws = 0) {
 // dst = a^-1 through the norm to Fp (a != 0); uses scratch slots t0, t1, t2 (all distinct from a)
 COOP_FN void coop_inv(CoopLds &L, int dst, int a, int t0, int t1, int t2, u32 lane, int ws = 0) {
     // t0 = frob_1(a) * frob_2(a) * ... * frob_5(a)
-    if (lane < 6) {
-        L.slot[t0][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * 1);
-        L.slot[t1][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * 2);
+    if (lane < 12) {
+        const int c = (int)(lane % 6u);
+        L.slot[t0][lane] = fp_mul_gpow(L.slot[a][lane], c * 1);
+        L.slot[t1][lane] = fp_mul_gpow(L.slot[a][lane], c * 2);
     }
     coop_sync();
     coop_mul(L, t0, t0, t1, lane, ws);
 #pragma unroll 1
     for (int k = 3; k <= 5; k++) {
-        if (lane < 6) L.slot[t1][lane] = fp_mul_gpow(L.slot[a][lane], (int)lane * k);
+        if (lane < 12) L.slot[t1][lane] = fp_mul_gpow(L.slot[a][lane], (int)(lane % 6u) * k);
         coop_sync();
         coop_mul(L, t0, t0, t1, lane, ws);
     }
@@ -131,55 +179,98 @@ COOP_FN void coop_inv(CoopLds &L, int dst, int a, int t0, int t1, int t2, u32 la
     coop_mul_fp(L, dst, t0, ninv, lane, ws);
 }
 
-// (X, Y, Z) <- 2 (X, Y, Z), dbl-2007-bl with a = 1; t[0..8] are nine scratch slots
+// (X, Y, Z) <- 2 (X, Y, Z), dbl-2007-bl with a = 1, as four product rounds and four linear steps (eight
+// LDS round trips instead of one per field operation); t[0..8] are scratch slots.  Within a linear step
+// no lane group writes a slot another group reads (the groups run as divergent branches, in no fixed order).
+//   R1  XX = X^2, YY = Y^2, ZZ = Z^2
+//   L1  T = X + YY, V = Y + Z, M3 = 3 XX
+//   R2  YYYY = YY^2, T = T^2, U = ZZ^2, V = V^2
+//   L2  S = 2 (T - XX - YYYY), M = M3 + U, Z3 = V - YY - ZZ, E = 8 YYYY
+//   R3  MM = M^2
+//   L3  X3 = MM - 2 S, W = S - X3
+//   R4  MW = M W
+//   L4  Y3 = MW - E
 COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lane, int ws = 0) {
-    const int XX = t[0], YY = t[1], YYYY = t[2], ZZ = t[3], T = t[4], S = t[5], M = t[6], U = t[7], V = t[8];
-    coop_mul(L, XX, X, X, lane, ws);
-    coop_mul(L, YY, Y, Y, lane, ws);
-    coop_mul(L, YYYY, YY, YY, lane, ws);
-    coop_mul(L, ZZ, Z, Z, lane, ws);
-    coop_add(L, T, X, YY, lane, ws);
-    coop_mul(L, T, T, T, lane, ws);
-    coop_sub(L, T, T, XX, lane, ws);
-    coop_sub(L, T, T, YYYY, lane, ws);
-    coop_add(L, S, T, T, lane, ws);            // S = 2((X+YY)^2 - XX - YYYY)
-    coop_add(L, M, XX, XX, lane, ws);
-    coop_add(L, M, M, XX, lane, ws);
-    coop_mul(L, U, ZZ, ZZ, lane, ws);
-    coop_add(L, M, M, U, lane, ws);            // M = 3XX + ZZ^2
-    coop_add(L, U, Y, Z, lane, ws);
-    coop_mul(L, U, U, U, lane, ws);
-    coop_sub(L, U, U, YY, lane, ws);
-    coop_sub(L, Z, U, ZZ, lane, ws);           // Z3 = (Y+Z)^2 - YY - ZZ
-    coop_mul(L, V, M, M, lane, ws);
-    coop_sub(L, V, V, S, lane, ws);
-    coop_sub(L, X, V, S, lane, ws);            // X3 = M^2 - 2S
-    coop_sub(L, V, S, X, lane, ws);
-    coop_mul(L, V, M, V, lane, ws);
-    coop_add(L, U, YYYY, YYYY, lane, ws);
-    coop_add(L, U, U, U, lane, ws);
-    coop_add(L, U, U, U, lane, ws);            // 8 YYYY
-    coop_sub(L, Y, V, U, lane, ws);            // Y3 = M (S - X3) - 8 YYYY
+    const int XX = t[0], YY = t[1], ZZ = t[2], T = t[3], V = t[4], M = t[5], YYYY = t[6], U = t[7], E = t[8];
+    const u32 g = lane / 12u, c = lane - 12u * g;
+    {
+        const int d[3] = {XX, YY, ZZ}, a[3] = {X, Y, Z};
+        coop_mul_round<3>(L, d, a, a, lane);
+    }
+    if (g == 0) {
+        L.slot[T][c] = fp_add(L.slot[X][c], L.slot[YY][c]);
+    } else if (g == 1) {
+        L.slot[V][c] = fp_add(L.slot[Y][c], L.slot[Z][c]);
+    } else if (g == 2) {
+        const u64 xx = L.slot[XX][c];
+        L.slot[M][c] = fp_add(fp_dbl(xx), xx);
+    }
+    coop_sync();
+    {
+        const int d[4] = {YYYY, T, U, V}, a[4] = {YY, T, ZZ, V};
+        coop_mul_round<4>(L, d, a, a, lane);
+    }
+    if (g == 0) {
+        const u64 s = fp_sub(fp_sub(L.slot[T][c], L.slot[XX][c]), L.slot[YYYY][c]);
+        L.slot[T][c] = fp_dbl(s);                                           // S
+    } else if (g == 1) {
+        L.slot[M][c] = fp_add(L.slot[M][c], L.slot[U][c]);                  // M
+    } else if (g == 2) {
+        L.slot[Z][c] = fp_sub(fp_sub(L.slot[V][c], L.slot[YY][c]), L.slot[ZZ][c]);   // Z3
+    } else if (g == 3) {
+        L.slot[E][c] = fp_dbl(fp_dbl(fp_dbl(L.slot[YYYY][c])));             // E (own slot: group 0 reads YYYY)
+    }
+    coop_sync();
+    coop_mul(L, XX, M, M, lane, ws);                                        // MM
+    if (g == 0) {
+        const u64 sv = L.slot[T][c];
+        const u64 x3 = fp_sub(L.slot[XX][c], fp_dbl(sv));
+        L.slot[X][c] = x3;
+        L.slot[YY][c] = fp_sub(sv, x3);                                     // W
+    }
+    coop_sync();
+    coop_mul(L, ZZ, M, YY, lane, ws);                                       // MW
+    if (g == 0) L.slot[Y][c] = fp_sub(L.slot[ZZ][c], L.slot[E][c]);
+    coop_sync();
 }
 
-// (X, Y, Z) <- (X, Y, Z) + (QX, QY) affine, (0, 0) = identity; same case analysis as jac_madd
+// (X, Y, Z) <- (X, Y, Z) + (QX, QY) affine, (0, 0) = identity; same case analysis as jac_madd.
+// Five product rounds and four linear steps; t[0..8] scratch.
+//   R1  Z1Z1 = Z^2
+//   R2  U2 = QX Z1Z1, ZZZ = Z Z1Z1
+//   L2  H = U2 - X
+//   R3  S2 = QY ZZZ, HH = H^2, Z3 = Z H
+//   L3  R = S2 - Y                           (H = 0: doubling or the identity, decided here)
+//   R4  HHH = H HH, V = X HH, W = R^2
+//   L4  X3 = W - HHH - 2 V, D = V - X3
+//   R5  RD = R D, YH = Y HHH
+//   L5  Y3 = RD - YH, Z = Z3
 COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, const int *t, u32 lane, int ws = 0) {
-    const int Z1Z1 = t[0], U2 = t[1], S2 = t[2], H = t[3], R = t[4], HH = t[5], HHH = t[6], V = t[7], W = t[8];
+    const int Z1Z1 = t[0], U2 = t[1], ZZZ = t[2], H = t[3], R = t[4], HH = t[5], Z3 = t[6], HHH = t[7], V = t[8];
+    const u32 g = lane / 12u, c = lane - 12u * g;
     const bool p_inf = coop_is_zero(L, Z, lane, ws);
     const bool q_inf = coop_is_zero(L, QX, lane, ws) && coop_is_zero(L, QY, lane, ws);
     if (q_inf) return;
     if (p_inf) {
-        coop_copy(L, X, QX, lane, ws);
-        coop_copy(L, Y, QY, lane, ws);
-        coop_set(L, Z, 1ull, lane, ws);
+        if (g == 0) L.slot[X][c] = L.slot[QX][c];
+        else if (g == 1) L.slot[Y][c] = L.slot[QY][c];
+        else if (g == 2) L.slot[Z][c] = c == 0 ? 1ull : (c == 6 ? 7ull : 0ull);
+        coop_sync();
         return;
     }
     coop_mul(L, Z1Z1, Z, Z, lane, ws);
-    coop_mul(L, U2, QX, Z1Z1, lane, ws);
-    coop_mul(L, S2, QY, Z, lane, ws);
-    coop_mul(L, S2, S2, Z1Z1, lane, ws);
-    coop_sub(L, H, U2, X, lane, ws);
-    coop_sub(L, R, S2, Y, lane, ws);
+    {
+        const int d[2] = {U2, ZZZ}, a[2] = {QX, Z}, b[2] = {Z1Z1, Z1Z1};
+        coop_mul_round<2>(L, d, a, b, lane);
+    }
+    if (g == 0) L.slot[H][c] = fp_sub(L.slot[U2][c], L.slot[X][c]);
+    coop_sync();
+    {
+        const int d[3] = {R, HH, Z3}, a[3] = {QY, H, Z}, b[3] = {ZZZ, H, H};
+        coop_mul_round<3>(L, d, a, b, lane);
+    }
+    if (g == 0) L.slot[R][c] = fp_sub(L.slot[R][c], L.slot[Y][c]);
+    coop_sync();
     if (coop_is_zero(L, H, lane, ws)) {
         if (coop_is_zero(L, R, lane, ws)) {
             coop_jac_dbl(L, X, Y, Z, t, lane, ws);      // p == q
@@ -188,18 +279,24 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
         }
         return;
     }
-    coop_mul(L, HH, H, H, lane, ws);
-    coop_mul(L, HHH, H, HH, lane, ws);
-    coop_mul(L, V, X, HH, lane, ws);
-    coop_mul(L, W, R, R, lane, ws);
-    coop_sub(L, W, W, HHH, lane, ws);
-    coop_sub(L, W, W, V, lane, ws);
-    coop_sub(L, X, W, V, lane, ws);                     // X3 = R^2 - HHH - 2V
-    coop_sub(L, V, V, X, lane, ws);
-    coop_mul(L, V, R, V, lane, ws);
-    coop_mul(L, W, Y, HHH, lane, ws);
-    coop_sub(L, Y, V, W, lane, ws);                     // Y3 = R (V - X3) - Y1 HHH
-    coop_mul(L, Z, Z, H, lane, ws);                     // Z3 = Z1 H
+    {
+        const int d[3] = {HHH, V, Z1Z1}, a[3] = {H, X, R}, b[3] = {HH, HH, R};   // Z1Z1 <- W = R^2
+        coop_mul_round<3>(L, d, a, b, lane);
+    }
+    if (g == 0) {
+        const u64 v = L.slot[V][c];
+        const u64 x3 = fp_sub(fp_sub(L.slot[Z1Z1][c], L.slot[HHH][c]), fp_dbl(v));
+        L.slot[X][c] = x3;
+        L.slot[U2][c] = fp_sub(v, x3);                  // D
+    }
+    coop_sync();
+    {
+        const int d[2] = {ZZZ, HH}, a[2] = {R, Y}, b[2] = {U2, HHH};             // ZZZ <- R D, HH <- Y HHH
+        coop_mul_round<2>(L, d, a, b, lane);
+    }
+    if (g == 0) L.slot[Y][c] = fp_sub(L.slot[ZZZ][c], L.slot[HH][c]);
+    else if (g == 1) L.slot[Z][c] = L.slot[Z3][c];
+    coop_sync();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,11 +501,12 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
     const sc256 e = ld_sc(sig + 49);
     if (ws == 0) {   // stage the inputs, canonical-limb checks
         bool pk_ok = true, sig_ok = true;
-        if (lane < 6) {
-            const u64 xs = ld_u64_le(sig + 8 * lane), px = ld_u64_le(pk + 8 * lane), py = ld_u64_le(pk + 48 + 8 * lane);
-            L.slot[SX][lane] = xs;
-            L.slot[PX][lane] = px;
-            L.slot[PY][lane] = py;
+        if (lane < 12) {
+            const u32 c = lane % 6u;
+            const u64 xs = ld_u64_le(sig + 8 * c), px = ld_u64_le(pk + 8 * c), py = ld_u64_le(pk + 48 + 8 * c);
+            coop_store7(L, SX, xs, lane);
+            coop_store7(L, PX, px, lane);
+            coop_store7(L, PY, py, lane);
             pk_ok = px < FP_P && py < FP_P;
             sig_ok = xs < FP_P;
         }
@@ -428,7 +526,7 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
             coop_mul(L, T0, PX, PX, lane, ws);
             coop_mul(L, T0, T0, PX, lane, ws);
             coop_add(L, T0, T0, PX, lane, ws);
-            if (lane < 2) L.slot[T0][lane] = fp_add(L.slot[T0][lane], lane == 0 ? 395ull : 1ull);
+            if (lane < 2) L.slot[T0][lane] = fp_add(L.slot[T0][lane], lane == 0 ? 395ull : 1ull);   // compared only
             coop_sync();
             coop_mul(L, T0 + 1, PY, PY, lane, ws);
             ok = coop_eq(L, T0, T0 + 1, lane, ws);
@@ -463,8 +561,11 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
                 const u32 d = sc_win16(e, (u32)w);
                 if (d != 0) {
                     const u64 *rowp = gtab + (((size_t)w << 16) + d) * 12;
-                    if (lane < 6) L.slot[QX][lane] = rowp[lane];
-                    else if (lane < 12) L.slot[QY][lane - 6] = rowp[lane];
+                    if (lane < 24) {   // lanes 0..11: x, 7x; lanes 12..23: y, 7y
+                        const u32 half = lane / 12u, c = lane % 12u;
+                        const u64 v = rowp[6u * half + c % 6u];
+                        L.slot[half ? QY : QX][c] = c < 6 ? v : fp_mul_small(v, 7u);
+                    }
                     coop_sync();
                     coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane, ws);
                 }

@@ -219,7 +219,11 @@ msm_k_shift(const u64 *__restrict__ win_in, MsmShape sh, u64 *__restrict__ win_o
     int t[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) t[k] = 3 + k;
-    if (lane < 18) L.slot[lane / 6][lane % 6] = win_in[18 * (size_t)j + lane];
+    if (lane < 36) {   // X, Y, Z with their 7x halves
+        const u32 v = lane / 12u, c = lane % 12u;
+        const u64 w = win_in[18 * (size_t)j + 6u * v + c % 6u];
+        L.slot[v][c] = c < 6 ? w : fp_mul_small(w, 7u);
+    }
     coop_sync();
 #pragma unroll 1
     for (u32 s = 0; s < j * sh.c; s++) coop_jac_dbl(L, 0, 1, 2, t, lane);
