@@ -62,7 +62,8 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     HIP_TRY(hipSetDevice(device));
     ssa_ctx *ctx = new ssa_ctx();
     ctx->device = device;
-    if (const char *cm = std::getenv("SSA_COOP_MAX_N")) ctx->coop_max_n = (size_t)std::strtoull(cm, nullptr, 10);
+    if (const char *cm = std::getenv("SSA_COOP_MAX_N"))
+        ctx->coop_max_n = ctx->coop_max_n_torsion = (size_t)std::strtoull(cm, nullptr, 10);
     if (const char *vb = std::getenv("SSA_VERIFY_BLOCK")) {
         const int v = std::atoi(vb);
         if (v == 64 || v == 128 || v == 256) ctx->verify_block = (unsigned)v;
@@ -211,7 +212,8 @@ extern "C" int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const
     if (n == 0) return 0;
     MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
     // small batches: one wave per signature (low latency); large ones: one lane per signature (throughput)
-    const bool coop = (flags & SSA_FLAG_FORCE_COOP) || (!(flags & SSA_FLAG_FORCE_LANE) && n <= ctx->coop_max_n);
+    const size_t coop_lim = (flags & SSA_FLAG_CHECK_TORSION) ? ctx->coop_max_n_torsion : ctx->coop_max_n;
+    const bool coop = (flags & SSA_FLAG_FORCE_COOP) || (!(flags & SSA_FLAG_FORCE_LANE) && n <= coop_lim);
     if (coop) {
         return timed_launch(ctx, "ssa_k_verify_coop", [&] {
             hipLaunchKernelGGL(ssa_k_verify_coop, dim3((unsigned)n), dim3(128), 0, ctx->stream, ctx->d_params, d_sigs,

@@ -179,97 +179,100 @@ COOP_FN void coop_inv(CoopLds &L, int dst, int a, int t0, int t1, int t2, u32 la
     coop_mul_fp(L, dst, t0, ninv, lane, ws);
 }
 
-// (X, Y, Z) <- 2 (X, Y, Z), dbl-2007-bl with a = 1, as four product rounds and four linear steps (eight
-// LDS round trips instead of one per field operation); t[0..8] are scratch slots.  Within a linear step
-// no lane group writes a slot another group reads (the groups run as divergent branches, in no fixed order).
-//   R1  XX = X^2, YY = Y^2, ZZ = Z^2
-//   L1  T = X + YY, V = Y + Z, M3 = 3 XX
-//   R2  YYYY = YY^2, T = T^2, U = ZZ^2, V = V^2
-//   L2  S = 2 (T - XX - YYYY), M = M3 + U, Z3 = V - YY - ZZ, E = 8 YYYY
-//   R3  MM = M^2
-//   L3  X3 = MM - 2 S, W = S - X3
-//   R4  MW = M W
-//   L4  Y3 = MW - E
+// Building blocks of a hand-scheduled round: lane k of a six-lane group computes coefficient k of A * B
+// (lazy accumulation, one reduction -- the arithmetic of the per-lane kernels), then the group applies the
+// additions that follow the product in the formula and stores value and 7x value.
+COOP_FN u64 coop_group_mul(const u64 *A, const u64 *B, u32 k) {
+    u64 x[6], y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        int idx = (int)k - i;          // b_{k-i}, or 7 b_{k-i+6} from the upper half
+        if (idx < 0) idx += 12;
+        x[i] = A[i];
+        y[i] = B[idx];
+    }
+    fp_acc acc;
+    acc_init(acc, x[0], y[0]);
+#pragma unroll
+    for (int i = 1; i < 6; i++) acc_mac(acc, x[i], y[i]);
+    return acc_reduce(acc);
+}
+COOP_FN void coop_put(CoopLds &L, int dst, u32 k, u64 r) {
+    L.slot[dst][k] = r;
+    L.slot[dst][6 + k] = fp_mul_small(r, 7u);
+}
+COOP_FN int coop_pick(u32 g, int s0, int s1, int s2 = 0, int s3 = 0) {
+    return g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : s3));
+}
+
+// (X, Y, Z) <- 2 (X, Y, Z), a = 1.  dbl-2007-bl with its squarings of sums turned back into products
+// (2 X YY = (X + YY)^2 - XX - YYYY, 2 Y Z = (Y + Z)^2 - YY - ZZ: with six lanes per product a product costs
+// what a square costs), so that every addition of the formula follows a product of its own lane group and the
+// doubling is FOUR rounds = four LDS round trips; t[0..5] scratch.
+//   R1  XX = X^2 -> M3 = 3 XX | YY = Y^2 | ZZ = Z^2 | Y Z -> Z3 = 2 Y Z
+//   R2  YY^2 -> E = 8 YYYY | X YY -> S = 4 X YY | ZZ^2 -> M = M3 + ZZ^2
+//   R3  M^2 -> X3 = M^2 - 2 S, W = S - X3
+//   R4  M W -> Y3 = M W - E
+// Within a round the product part (uniform code) reads, the per-group tails write: no tail reads a slot that
+// another group's tail writes.
 COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lane, int ws = 0) {
-    const int XX = t[0], YY = t[1], ZZ = t[2], T = t[3], V = t[4], M = t[5], YYYY = t[6], U = t[7], E = t[8];
-    const u32 g = lane / 12u, c = lane - 12u * g;
-    {
-        const int d[3] = {XX, YY, ZZ}, a[3] = {X, Y, Z};
-        coop_mul_round<3>(L, d, a, a, lane);
-    }
+    const int YY = t[0], ZZ = t[1], M = t[2], E = t[3], S = t[4], W = t[5];
+    const u32 g = lane / 6u, k = lane - 6u * g;
+    u64 r = 0;
+    if (g < 4) r = coop_group_mul(L.slot[coop_pick(g, X, Y, Z, Y)], L.slot[coop_pick(g, X, Y, Z, Z)], k);
+    if (g == 0) coop_put(L, M, k, fp_add(fp_dbl(r), r));
+    else if (g == 1) coop_put(L, YY, k, r);
+    else if (g == 2) coop_put(L, ZZ, k, r);
+    else if (g == 3) coop_put(L, Z, k, fp_dbl(r));
+    coop_sync();
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, YY, X, ZZ)], L.slot[coop_pick(g, YY, YY, ZZ)], k);
+    if (g == 0) coop_put(L, E, k, fp_dbl(fp_dbl(fp_dbl(r))));
+    else if (g == 1) coop_put(L, S, k, fp_dbl(fp_dbl(r)));
+    else if (g == 2) coop_put(L, M, k, fp_add(r, L.slot[M][k]));
+    coop_sync();
     if (g == 0) {
-        L.slot[T][c] = fp_add(L.slot[X][c], L.slot[YY][c]);
-    } else if (g == 1) {
-        L.slot[V][c] = fp_add(L.slot[Y][c], L.slot[Z][c]);
-    } else if (g == 2) {
-        const u64 xx = L.slot[XX][c];
-        L.slot[M][c] = fp_add(fp_dbl(xx), xx);
+        r = coop_group_mul(L.slot[M], L.slot[M], k);
+        const u64 sv = L.slot[S][k];
+        const u64 x3 = fp_sub(r, fp_dbl(sv));
+        coop_put(L, X, k, x3);
+        coop_put(L, W, k, fp_sub(sv, x3));
     }
     coop_sync();
-    {
-        const int d[4] = {YYYY, T, U, V}, a[4] = {YY, T, ZZ, V};
-        coop_mul_round<4>(L, d, a, a, lane);
-    }
     if (g == 0) {
-        const u64 s = fp_sub(fp_sub(L.slot[T][c], L.slot[XX][c]), L.slot[YYYY][c]);
-        L.slot[T][c] = fp_dbl(s);                                           // S
-    } else if (g == 1) {
-        L.slot[M][c] = fp_add(L.slot[M][c], L.slot[U][c]);                  // M
-    } else if (g == 2) {
-        L.slot[Z][c] = fp_sub(fp_sub(L.slot[V][c], L.slot[YY][c]), L.slot[ZZ][c]);   // Z3
-    } else if (g == 3) {
-        L.slot[E][c] = fp_dbl(fp_dbl(fp_dbl(L.slot[YYYY][c])));             // E (own slot: group 0 reads YYYY)
+        r = coop_group_mul(L.slot[M], L.slot[W], k);
+        coop_put(L, Y, k, fp_sub(r, L.slot[E][k]));
     }
-    coop_sync();
-    coop_mul(L, XX, M, M, lane, ws);                                        // MM
-    if (g == 0) {
-        const u64 sv = L.slot[T][c];
-        const u64 x3 = fp_sub(L.slot[XX][c], fp_dbl(sv));
-        L.slot[X][c] = x3;
-        L.slot[YY][c] = fp_sub(sv, x3);                                     // W
-    }
-    coop_sync();
-    coop_mul(L, ZZ, M, YY, lane, ws);                                       // MW
-    if (g == 0) L.slot[Y][c] = fp_sub(L.slot[ZZ][c], L.slot[E][c]);
     coop_sync();
 }
 
-// (X, Y, Z) <- (X, Y, Z) + (QX, QY) affine, (0, 0) = identity; same case analysis as jac_madd.
-// Five product rounds and four linear steps; t[0..8] scratch.
-//   R1  Z1Z1 = Z^2
-//   R2  U2 = QX Z1Z1, ZZZ = Z Z1Z1
-//   L2  H = U2 - X
-//   R3  S2 = QY ZZZ, HH = H^2, Z3 = Z H
-//   L3  R = S2 - Y                           (H = 0: doubling or the identity, decided here)
-//   R4  HHH = H HH, V = X HH, W = R^2
-//   L4  X3 = W - HHH - 2 V, D = V - X3
-//   R5  RD = R D, YH = Y HHH
-//   L5  Y3 = RD - YH, Z = Z3
+// (X, Y, Z) <- (X, Y, Z) + (QX, QY) affine, (0, 0) = identity; same case analysis as jac_madd.  Five rounds;
+// where an addition needs the product of a neighbouring group the value crosses by a wave shuffle.
+//   R1  Z1Z1 = Z^2 | QY Z
+//   R2  QX Z1Z1 -> H = U2 - X | (QY Z) Z1Z1 -> R = S2 - Y           (H = 0: doubling or the identity)
+//   R3  HH = H^2 | Z3 = Z H | W = R^2
+//   R4  HHH = H HH | V = X HH -> X3 = W - HHH - 2 V, D = V - X3
+//   R5  R D | Y HHH -> Y3 = R D - Y HHH
 COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, const int *t, u32 lane, int ws = 0) {
-    const int Z1Z1 = t[0], U2 = t[1], ZZZ = t[2], H = t[3], R = t[4], HH = t[5], Z3 = t[6], HHH = t[7], V = t[8];
-    const u32 g = lane / 12u, c = lane - 12u * g;
+    const int Z1Z1 = t[0], QYZ = t[1], H = t[2], R = t[3], HH = t[4], W = t[5], HHH = t[6], D = t[7];
+    const u32 g = lane / 6u, k = lane - 6u * g;
     const bool p_inf = coop_is_zero(L, Z, lane, ws);
     const bool q_inf = coop_is_zero(L, QX, lane, ws) && coop_is_zero(L, QY, lane, ws);
     if (q_inf) return;
     if (p_inf) {
-        if (g == 0) L.slot[X][c] = L.slot[QX][c];
-        else if (g == 1) L.slot[Y][c] = L.slot[QY][c];
-        else if (g == 2) L.slot[Z][c] = c == 0 ? 1ull : (c == 6 ? 7ull : 0ull);
+        if (g == 0) coop_put(L, X, k, L.slot[QX][k]);
+        else if (g == 1) coop_put(L, Y, k, L.slot[QY][k]);
+        else if (g == 2) coop_put(L, Z, k, k == 0 ? 1ull : 0ull);
         coop_sync();
         return;
     }
-    coop_mul(L, Z1Z1, Z, Z, lane, ws);
-    {
-        const int d[2] = {U2, ZZZ}, a[2] = {QX, Z}, b[2] = {Z1Z1, Z1Z1};
-        coop_mul_round<2>(L, d, a, b, lane);
-    }
-    if (g == 0) L.slot[H][c] = fp_sub(L.slot[U2][c], L.slot[X][c]);
+    u64 r = 0;
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, Z, QY)], L.slot[Z], k);
+    if (g == 0) coop_put(L, Z1Z1, k, r);
+    else if (g == 1) coop_put(L, QYZ, k, r);
     coop_sync();
-    {
-        const int d[3] = {R, HH, Z3}, a[3] = {QY, H, Z}, b[3] = {ZZZ, H, H};
-        coop_mul_round<3>(L, d, a, b, lane);
-    }
-    if (g == 0) L.slot[R][c] = fp_sub(L.slot[R][c], L.slot[Y][c]);
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, QX, QYZ)], L.slot[Z1Z1], k);
+    if (g == 0) coop_put(L, H, k, fp_sub(r, L.slot[X][k]));
+    else if (g == 1) coop_put(L, R, k, fp_sub(r, L.slot[Y][k]));
     coop_sync();
     if (coop_is_zero(L, H, lane, ws)) {
         if (coop_is_zero(L, R, lane, ws)) {
@@ -279,23 +282,28 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
         }
         return;
     }
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, Z, R)], L.slot[coop_pick(g, H, H, R)], k);
+    if (g == 0) coop_put(L, HH, k, r);
+    else if (g == 1) coop_put(L, Z, k, r);
+    else if (g == 2) coop_put(L, W, k, r);
+    coop_sync();
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, H, X)], L.slot[HH], k);
     {
-        const int d[3] = {HHH, V, Z1Z1}, a[3] = {H, X, R}, b[3] = {HH, HH, R};   // Z1Z1 <- W = R^2
-        coop_mul_round<3>(L, d, a, b, lane);
-    }
-    if (g == 0) {
-        const u64 v = L.slot[V][c];
-        const u64 x3 = fp_sub(fp_sub(L.slot[Z1Z1][c], L.slot[HHH][c]), fp_dbl(v));
-        L.slot[X][c] = x3;
-        L.slot[U2][c] = fp_sub(v, x3);                  // D
+        const u64 hhh = __shfl(r, (int)k);              // group 0's product, seen by every group
+        if (g == 0) {
+            coop_put(L, HHH, k, r);
+        } else if (g == 1) {
+            const u64 x3 = fp_sub(fp_sub(L.slot[W][k], hhh), fp_dbl(r));
+            coop_put(L, X, k, x3);
+            coop_put(L, D, k, fp_sub(r, x3));
+        }
     }
     coop_sync();
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, R, Y)], L.slot[coop_pick(g, D, HHH)], k);
     {
-        const int d[2] = {ZZZ, HH}, a[2] = {R, Y}, b[2] = {U2, HHH};             // ZZZ <- R D, HH <- Y HHH
-        coop_mul_round<2>(L, d, a, b, lane);
+        const u64 yh = __shfl(r, (int)(6u + k));        // group 1's product
+        if (g == 0) coop_put(L, Y, k, fp_sub(r, yh));
     }
-    if (g == 0) L.slot[Y][c] = fp_sub(L.slot[ZZZ][c], L.slot[HH][c]);
-    else if (g == 1) L.slot[Z][c] = L.slot[Z3][c];
     coop_sync();
 }
 

@@ -62,7 +62,9 @@ struct ssa_ctx {
     DevBuf msm_points, msm_scalars, msm_keys, msm_vals, msm_keys2, msm_vals2, msm_sort_tmp, msm_bounds,
         msm_buckets, msm_chunks, msm_windows, msm_partials, msm_flags, st_coeffs;
     bool timing = false;
-    size_t coop_max_n = 5120;     // batches up to this size take the wave-per-signature kernel (measured crossover; SSA_COOP_MAX_N)
+    // batches up to these sizes take the cooperative (waves-per-signature) kernel: measured crossovers without /
+    // with the subgroup check (tools/mode_crossover.py); SSA_COOP_MAX_N overrides both
+    size_t coop_max_n = 5632, coop_max_n_torsion = 8192;
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;
 };

@@ -882,6 +882,7 @@ def test_auto_dispatch_agrees_across_the_threshold(engine):
     sigs[bad, 52] ^= 4
     expect = np.zeros(n, dtype=np.uint8)
     expect[bad] = 2
-    for cut in (1, 100, 5120, 5121, n):
-        st, nf = engine.verify_many(sigs[:cut], pks[:cut], msgs[:cut], check_torsion=True)
-        assert (st == expect[:cut]).all() and nf == int((expect[:cut] != 0).sum())
+    for torsion, cuts in ((True, (1, 100, 8192, 8193, n)), (False, (5632, 5633))):
+        for cut in cuts:
+            st, nf = engine.verify_many(sigs[:cut], pks[:cut], msgs[:cut], check_torsion=torsion)
+            assert (st == expect[:cut]).all() and nf == int((expect[:cut] != 0).sum())
