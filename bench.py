@@ -13,6 +13,7 @@ the only exchange is one 8-byte all-reduce of the rejection counts per step (RCC
 """
 import argparse
 import json
+import numpy as np
 import os
 import sys
 import time
@@ -296,6 +297,20 @@ def main():
                           "(oracle/schnorr_oracle.c, -O3 -march=native, OpenMP), verify_batch semantics" % m,
                 "agrees_with_gpu": bool((st == gpu_st).all()),
             }
+            # the same restatement the way the reference runs it: one thread (it has no threading), per
+            # signature with the subgroup check, and its MSM-form verify_batch
+            m1 = min(1024, m)
+            tc = time.perf_counter()
+            orc.verify_many(hs[:m1], hp[:m1], hm[:m1], check_torsion=True, threads=1)
+            t_one = time.perf_counter() - tc
+            co = np.random.default_rng(11).integers(0, 256, size=(m1, 32), dtype=np.uint8)
+            co[:, 16:] = 0
+            tc = time.perf_counter()
+            verdict_cpu = orc.verify_batch_msm(hs[:m1], hp[:m1], hm[:m1], co, threads=1)
+            t_msm = time.perf_counter() - tc
+            out["cpu_baseline"]["single_thread"] = {
+                "signature_verify_per_sec": m1 / t_one, "verify_batch_msm_form_signatures_per_sec": m1 / t_msm,
+                "verify_batch_msm_form_verdict": verdict_cpu, "sample": "first %d signatures, 1 thread" % m1}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

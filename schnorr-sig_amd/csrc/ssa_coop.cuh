@@ -86,44 +86,6 @@ COOP_FN void coop_mul(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
     coop_sync();
 }
 
-// N independent products in ONE LDS round trip: six lanes per product, lane k of a group accumulates the
-// six terms of output coefficient k lazily (the arithmetic of the per-lane kernels) and reduces once.
-// dst may alias a source: every lane reads before any lane writes (one wave, in-order LDS).
-template <int N>
-COOP_FN void coop_mul_round(CoopLds &L, const int (&dst)[N], const int (&a)[N], const int (&b)[N], u32 lane) {
-    static_assert(N >= 1 && N <= 10, "six lanes per product");
-    const u32 g = lane / 6u, k = lane - 6u * g;
-    if (g < (u32)N) {
-        int sa = a[0], sb = b[0], sd = dst[0];
-#pragma unroll
-        for (int n = 1; n < N; n++) {
-            if (g == (u32)n) {
-                sa = a[n];
-                sb = b[n];
-                sd = dst[n];
-            }
-        }
-        const u64 *A = L.slot[sa], *B = L.slot[sb];
-        u64 x[6], y[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            int idx = (int)k - i;          // b_{k-i}, or 7 b_{k-i+6} from the upper half
-            if (idx < 0) idx += 12;
-            x[i] = A[i];
-            y[i] = B[idx];
-        }
-        fp_acc acc;
-        acc_init(acc, x[0], y[0]);
-#pragma unroll
-        for (int i = 1; i < 6; i++) acc_mac(acc, x[i], y[i]);
-        const u64 r = acc_reduce(acc);
-        u64 *D = L.slot[sd];
-        D[k] = r;
-        D[6 + k] = fp_mul_small(r, 7u);
-    }
-    coop_sync();
-}
-
 // linear steps: the same operation on both halves of a slot (7 (a + b) = 7a + 7b)
 COOP_FN void coop_add(CoopLds &L, int dst, int a, int b, u32 lane, int ws = 0) {
     if (lane < 12) L.slot[dst][lane] = fp_add(L.slot[a][lane], L.slot[b][lane]);
@@ -303,6 +265,76 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
     {
         const u64 yh = __shfl(r, (int)(6u + k));        // group 1's product
         if (g == 0) coop_put(L, Y, k, fp_sub(r, yh));
+    }
+    coop_sync();
+}
+
+// (X1, Y1, Z1) <- (X1, Y1, Z1) + (X2, Y2, Z2), both Jacobian (add-1998-cmo-2), Z = 0 is the identity.
+// Five rounds; t[0..8] scratch.
+//   R1  A = Z1^2 | B = Z2^2 | C = Y1 Z2 | D = Y2 Z1 | E = Z1 Z2
+//   R2  U1 = X1 B | X2 A -> H = U2 - U1 | S1 = C B | D A -> R = S2 - S1      (H = 0: doubling or the identity)
+//   R3  HH = H^2 | Z3 = E H | W = R^2
+//   R4  HHH = H HH | V = U1 HH -> X3 = W - HHH - 2 V, F = V - X3
+//   R5  R F | S1 HHH -> Y3 = R F - S1 HHH
+COOP_FN void coop_jac_add(CoopLds &L, int X1, int Y1, int Z1, int X2, int Y2, int Z2, const int *t, u32 lane,
+                          int ws = 0) {
+    const int A = t[0], B = t[1], C = t[2], Dd = t[3], E = t[4], U1 = t[5], S1 = t[6], H = t[7], R = t[8];
+    const int HH = t[0], W = t[1], HHH = t[2], F = t[3];
+    const u32 g = lane / 6u, k = lane - 6u * g;
+    if (coop_is_zero(L, Z2, lane, ws)) return;
+    if (coop_is_zero(L, Z1, lane, ws)) {
+        if (g == 0) coop_put(L, X1, k, L.slot[X2][k]);
+        else if (g == 1) coop_put(L, Y1, k, L.slot[Y2][k]);
+        else if (g == 2) coop_put(L, Z1, k, L.slot[Z2][k]);
+        coop_sync();
+        return;
+    }
+    u64 r = 0;
+    if (g < 5) {
+        const int sa = g == 0 ? Z1 : (g == 1 ? Z2 : (g == 2 ? Y1 : (g == 3 ? Y2 : Z1)));
+        const int sb = g == 0 ? Z1 : (g == 1 ? Z2 : (g == 2 ? Z2 : (g == 3 ? Z1 : Z2)));
+        r = coop_group_mul(L.slot[sa], L.slot[sb], k);
+        coop_put(L, g == 0 ? A : (g == 1 ? B : (g == 2 ? C : (g == 3 ? Dd : E))), k, r);
+    }
+    coop_sync();
+    if (g < 4) r = coop_group_mul(L.slot[coop_pick(g, X1, X2, C, Dd)], L.slot[coop_pick(g, B, A, B, A)], k);
+    {
+        const u64 u1 = __shfl(r, (int)k), s1 = __shfl(r, (int)(12u + k));
+        if (g == 0) coop_put(L, U1, k, r);
+        else if (g == 1) coop_put(L, H, k, fp_sub(r, u1));
+        else if (g == 2) coop_put(L, S1, k, r);
+        else if (g == 3) coop_put(L, R, k, fp_sub(r, s1));
+    }
+    coop_sync();
+    if (coop_is_zero(L, H, lane, ws)) {
+        if (coop_is_zero(L, R, lane, ws)) {
+            coop_jac_dbl(L, X1, Y1, Z1, t, lane, ws);   // same point
+        } else {
+            coop_set(L, Z1, 0ull, lane, ws);            // opposite points
+        }
+        return;
+    }
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, E, R)], L.slot[coop_pick(g, H, H, R)], k);
+    if (g == 0) coop_put(L, HH, k, r);
+    else if (g == 1) coop_put(L, Z1, k, r);
+    else if (g == 2) coop_put(L, W, k, r);
+    coop_sync();
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, H, U1)], L.slot[HH], k);
+    {
+        const u64 hhh = __shfl(r, (int)k);
+        if (g == 0) {
+            coop_put(L, HHH, k, r);
+        } else if (g == 1) {
+            const u64 x3 = fp_sub(fp_sub(L.slot[W][k], hhh), fp_dbl(r));
+            coop_put(L, X1, k, x3);
+            coop_put(L, F, k, fp_sub(r, x3));
+        }
+    }
+    coop_sync();
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, R, S1)], L.slot[coop_pick(g, F, HHH)], k);
+    {
+        const u64 sh = __shfl(r, (int)(6u + k));
+        if (g == 0) coop_put(L, Y1, k, fp_sub(r, sh));
     }
     coop_sync();
 }

@@ -13,10 +13,10 @@
 //   3. msm_k_buckets   ONE BUCKET PER LANE: a lane adds up the points of its bucket with mixed
 //                      additions (every exceptional case handled: equal public keys land in one bucket)
 //   4. msm_k_chunks    running-sum trick on chunks of 8 buckets (short chains, 2^17 lanes);
-//                      msm_k_tree (x5) sums the chunk sums of a window; msm_k_shift multiplies window j
-//                      by 2^(c j) with ONE WAVE PER POINT (wave-cooperative Fp6 arithmetic: the only long
-//                      sequential chain of the method); msm_k_finish adds the windows, computes [lin]G
-//                      from the comb table and compares the x coordinates
+//                      msm_k_tree (x5) sums the chunk sums of a window; msm_k_finish is ONE cooperative
+//                      block: wave 0 combines the windows by Horner's rule (the only long sequential chain
+//                      of the method, ~240 doublings, wave-cooperative Fp6 arithmetic), wave 1 computes
+//                      [lin]G from the comb table meanwhile; then the x coordinates are compared
 // Panics of the reference (undecodable x, x not on the curve: src/batch.rs:67,104) give SSA_MALFORMED.
 #define SSA_NO_KERNELS 1
 #include "ssa_ctx.hpp"
@@ -209,59 +209,109 @@ msm_k_tree(const u64 *__restrict__ in, u32 windows, u32 count, u32 group, u64 *_
 }
 
 // ---- the one sequential chain of the reduction ---------------------------------------------------
-// Shifting window j by 2^(c j) is a chain of up to 240 dependent doublings.  A lone lane runs it at a
-// few percent of a SIMD's issue rate (measured: ~80 us per doubling), so one WAVE works on one point
-// (wave-cooperative Fp6 arithmetic, ssa_coop.cuh): ~5 us per doubling.
-__global__ void __launch_bounds__(64)
-msm_k_shift(const u64 *__restrict__ win_in, MsmShape sh, u64 *__restrict__ win_out) {
-    __shared__ CoopLds L;
-    const u32 j = blockIdx.x, lane = threadIdx.x;
-    int t[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) t[k] = 3 + k;
-    if (lane < 36) {   // X, Y, Z with their 7x halves
-        const u32 v = lane / 12u, c = lane % 12u;
-        const u64 w = win_in[18 * (size_t)j + 6u * v + c % 6u];
-        L.slot[v][c] = c < 6 ? w : fp_mul_small(w, 7u);
-    }
-    coop_sync();
-#pragma unroll 1
-    for (u32 s = 0; s < j * sh.c; s++) coop_jac_dbl(L, 0, 1, 2, t, lane);
-    if (lane < 18) win_out[18 * (size_t)j + lane] = L.slot[lane / 6][lane % 6];
-}
-
-// left = sum_j W_j ; right = [lin] G ; verdict: x-only comparison (src/batch.rs:125-129)
-__global__ void __launch_bounds__(64, 2)
+// left = sum_j 2^(c j) W_j by Horner's rule: (windows - 1) x (c doublings + one addition), a chain of ~240
+// dependent doublings.  A lone lane ran it at ~80 us per doubling; here wave 0 of the block works on the
+// one point (wave-cooperative Fp6 arithmetic, ssa_coop.cuh: ~2.5 us per doubling) while wave 1 adds up
+// lin = sum of the blocks' partial sums and computes right = [lin] G from the comb table.
+// Verdict: x-only comparison, left.get_x() == right.get_x() (src/batch.rs:98-100, :125-129).
+__global__ void __launch_bounds__(128)
 msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict__ partials, u32 n_partials,
              const u64 *__restrict__ gtab, const u32 *__restrict__ malformed, u32 *__restrict__ verdict) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    if (*malformed) {
-        *verdict = ST_MALFORMED;
+    __shared__ CoopLds L;
+    __shared__ u64 lin_sh[64][4];
+    const u32 lane = threadIdx.x & 63u;
+    const int ws = (int)(threadIdx.x >> 6);
+    if (*malformed) {   // block-uniform
+        if (threadIdx.x == 0) *verdict = ST_MALFORMED;
         return;
     }
-    jac left = jac_identity();
-#pragma unroll 1
-    for (u32 j = 0; j < sh.windows; j++) left = jac_add(left, ld_jac(win_in + 18 * (size_t)j));
-    sc256 lin;
+    // slots: wave 0 accumulator 0..2, addend 3..5, scratch 6..14; wave 1 accumulator 20..22, addend 23..24, scratch 25..33
+    int t[9];
 #pragma unroll
-    for (int k = 0; k < 4; k++) lin.w[k] = 0;
+    for (int k = 0; k < 9; k++) t[k] = (ws ? 25 : 6) + k;
+    if (ws == 0) {
+        auto load = [&](int s0, u32 j) {   // X, Y, Z of window j with their 7x halves
+            if (lane < 36) {
+                const u32 v = lane / 12u, c = lane % 12u;
+                const u64 w = win_in[18 * (size_t)j + 6u * v + c % 6u];
+                L.slot[s0 + (int)v][c] = c < 6 ? w : fp_mul_small(w, 7u);
+            }
+            coop_sync();
+        };
+        load(0, sh.windows - 1);
 #pragma unroll 1
-    for (u32 b = 0; b < n_partials; b++) {
-        sc256 p;
-#pragma unroll
-        for (int k = 0; k < 4; k++) p.w[k] = partials[4 * b + k];
-        lin = sc_add_mod(lin, p);
-    }
-    const jac right = add_base_mul(jac_identity(), gtab, lin);     // BASEPOINT_TABLE.multiply_vartime, :98-100
-    // left.get_x() == scaled_basepoint.get_x(): X_l Z_r^2 == X_r Z_l^2; the identity's x is taken as 0
-    const bool li = jac_is_identity(left), ri = jac_is_identity(right);
-    bool eq;
-    if (li || ri) {
-        eq = (li && ri) || (li && f6_is_zero(right.X)) || (ri && f6_is_zero(left.X));
+        for (int j = (int)sh.windows - 2; j >= 0; j--) {
+#pragma unroll 1
+            for (u32 d = 0; d < sh.c; d++) coop_jac_dbl(L, 0, 1, 2, t, lane, ws);
+            load(3, (u32)j);
+            coop_jac_add(L, 0, 1, 2, 3, 4, 5, t, lane, ws);
+        }
     } else {
-        eq = f6_eq(f6_mul(left.X, f6_sqr(right.Z)), f6_mul(right.X, f6_sqr(left.Z)));
+        sc256 acc;
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc.w[k] = 0;
+#pragma unroll 1
+        for (u32 b = lane; b < n_partials; b += 64) {
+            sc256 p;
+#pragma unroll
+            for (int k = 0; k < 4; k++) p.w[k] = partials[4 * b + k];
+            acc = sc_add_mod(acc, p);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) lin_sh[lane][k] = acc.w[k];
+        coop_sync();
+#pragma unroll 1
+        for (u32 stride = 32; stride >= 1; stride >>= 1) {
+            if (lane < stride) {
+                sc256 a, b;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    a.w[k] = lin_sh[lane][k];
+                    b.w[k] = lin_sh[lane + stride][k];
+                }
+                a = sc_add_mod(a, b);
+#pragma unroll
+                for (int k = 0; k < 4; k++) lin_sh[lane][k] = a.w[k];
+            }
+            coop_sync();
+        }
+        sc256 lin;
+#pragma unroll
+        for (int k = 0; k < 4; k++) lin.w[k] = lin_sh[0][k];
+        coop_set(L, 20, 1ull, lane, ws);
+        coop_set(L, 21, 1ull, lane, ws);
+        coop_set(L, 22, 0ull, lane, ws);
+#pragma unroll 1
+        for (int w = 0; w < GW_COUNT; w++) {      // BASEPOINT_TABLE.multiply_vartime
+            const u32 d = sc_win16(lin, (u32)w);
+            if (d != 0) {
+                const u64 *rowp = gtab + (((size_t)w << GW_BITS) + d) * 12;
+                if (lane < 24) {
+                    const u32 half = lane / 12u, c = lane % 12u;
+                    const u64 v = rowp[6u * half + c % 6u];
+                    L.slot[half ? 24 : 23][c] = c < 6 ? v : fp_mul_small(v, 7u);
+                }
+                coop_sync();
+                coop_jac_madd(L, 20, 21, 22, 23, 24, t, lane, ws);
+            }
+        }
     }
-    *verdict = eq ? ST_OK : ST_INVALID_SIG;
+    __syncthreads();
+    if (ws == 0) {
+        // X_l Z_r^2 == X_r Z_l^2; the identity's x is taken as 0
+        const bool li = coop_is_zero(L, 2, lane, ws), ri = coop_is_zero(L, 22, lane, ws);
+        bool eq;
+        if (li || ri) {
+            eq = (li && ri) || (li && coop_is_zero(L, 20, lane, ws)) || (ri && coop_is_zero(L, 0, lane, ws));
+        } else {
+            coop_mul(L, 6, 22, 22, lane, ws);
+            coop_mul(L, 6, 0, 6, lane, ws);
+            coop_mul(L, 7, 2, 2, lane, ws);
+            coop_mul(L, 7, 20, 7, lane, ws);
+            eq = coop_eq(L, 6, 7, lane, ws);
+        }
+        if (lane == 0) *verdict = eq ? ST_OK : ST_INVALID_SIG;
+    }
 }
 
 }  // namespace ssa
@@ -338,8 +388,8 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
     });
     if (rc) return rc;
     return timed_launch(ctx, "msm_reduce", [&] {
-        // per window: running sums on chunks of MSM_CHUNK buckets, a tree over the chunk sums, the
-        // 2^(c j) shift by one cooperating wave per window, then the final sum and comparison
+        // per window: running sums on chunks of MSM_CHUNK buckets, a tree over the chunk sums, then one
+        // cooperative block: Horner over the windows || [lin]G, and the comparison
         hipLaunchKernelGGL(msm_k_chunks, dim3(grid_for((size_t)sh.windows * sh.chunks, 256)), dim3(256), 0,
                            ctx->stream, (const u64 *)ctx->msm_buckets.p, sh, (u64 *)ctx->msm_chunks.p);
         u64 *ping = (u64 *)ctx->msm_chunks.p, *pong = (u64 *)ctx->msm_windows.p;
@@ -353,8 +403,7 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
             pong = tmp;
             count = groups;
         }
-        hipLaunchKernelGGL(msm_k_shift, dim3(sh.windows), dim3(64), 0, ctx->stream, (const u64 *)ping, sh, pong);
-        hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)pong, sh,
+        hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(128), 0, ctx->stream, (const u64 *)ping, sh,
                            (const u64 *)ctx->msm_partials.p, n_blocks, (const u64 *)ctx->d_gtab,
                            (const u32 *)ctx->msm_flags.p, d_verdict_out);
     });
