@@ -143,7 +143,8 @@ COOP_FN void coop_inv(CoopLds &L, int dst, int a, int t0, int t1, int t2, u32 la
 
 // Building blocks of a hand-scheduled round: lane k of a six-lane group computes coefficient k of A * B
 // (lazy accumulation, one reduction -- the arithmetic of the per-lane kernels), then the group applies the
-// additions that follow the product in the formula and stores value and 7x value.
+// additions that follow the product in the formula and stores the value -- with its 7x half (coop_put) when
+// the value will be the SECOND operand of a later product, which is the one read through the wrapped terms.
 COOP_FN u64 coop_group_mul(const u64 *A, const u64 *B, u32 k) {
     u64 x[6], y[6];
 #pragma unroll
@@ -182,27 +183,29 @@ COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lan
     const u32 g = lane / 6u, k = lane - 6u * g;
     u64 r = 0;
     if (g < 4) r = coop_group_mul(L.slot[coop_pick(g, X, Y, Z, Y)], L.slot[coop_pick(g, X, Y, Z, Z)], k);
-    if (g == 0) coop_put(L, M, k, fp_add(fp_dbl(r), r));
+    if (g == 0) L.slot[M][k] = fp_add(fp_dbl(r), r);          // M3: a tail operand only, no 7x half
     else if (g == 1) coop_put(L, YY, k, r);
     else if (g == 2) coop_put(L, ZZ, k, r);
     else if (g == 3) coop_put(L, Z, k, fp_dbl(r));
     coop_sync();
+    u64 pre = L.slot[M][k];     // tail operands are fetched before the products: their LDS latency hides
     if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, YY, X, ZZ)], L.slot[coop_pick(g, YY, YY, ZZ)], k);
-    if (g == 0) coop_put(L, E, k, fp_dbl(fp_dbl(fp_dbl(r))));
-    else if (g == 1) coop_put(L, S, k, fp_dbl(fp_dbl(r)));
-    else if (g == 2) coop_put(L, M, k, fp_add(r, L.slot[M][k]));
+    if (g == 0) L.slot[E][k] = fp_dbl(fp_dbl(fp_dbl(r)));        // E, S: read by tails only, no 7x half
+    else if (g == 1) L.slot[S][k] = fp_dbl(fp_dbl(r));
+    else if (g == 2) coop_put(L, M, k, fp_add(r, pre));
     coop_sync();
     if (g == 0) {
+        pre = L.slot[S][k];
         r = coop_group_mul(L.slot[M], L.slot[M], k);
-        const u64 sv = L.slot[S][k];
-        const u64 x3 = fp_sub(r, fp_dbl(sv));
+        const u64 x3 = fp_sub(r, fp_dbl(pre));
         coop_put(L, X, k, x3);
-        coop_put(L, W, k, fp_sub(sv, x3));
+        L.slot[W][k] = fp_sub(pre, x3);     // W is only ever a first operand: no 7x half needed
     }
     coop_sync();
     if (g == 0) {
+        pre = L.slot[E][k];
         r = coop_group_mul(L.slot[M], L.slot[W], k);
-        coop_put(L, Y, k, fp_sub(r, L.slot[E][k]));
+        coop_put(L, Y, k, fp_sub(r, pre));
     }
     coop_sync();
 }
@@ -230,11 +233,12 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
     u64 r = 0;
     if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, Z, QY)], L.slot[Z], k);
     if (g == 0) coop_put(L, Z1Z1, k, r);
-    else if (g == 1) coop_put(L, QYZ, k, r);
+    else if (g == 1) L.slot[QYZ][k] = r;                    // only ever a first operand: no 7x half
     coop_sync();
+    u64 pre = L.slot[coop_pick(g, X, Y)][k];
     if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, QX, QYZ)], L.slot[Z1Z1], k);
-    if (g == 0) coop_put(L, H, k, fp_sub(r, L.slot[X][k]));
-    else if (g == 1) coop_put(L, R, k, fp_sub(r, L.slot[Y][k]));
+    if (g == 0) coop_put(L, H, k, fp_sub(r, pre));
+    else if (g == 1) coop_put(L, R, k, fp_sub(r, pre));
     coop_sync();
     if (coop_is_zero(L, H, lane, ws)) {
         if (coop_is_zero(L, R, lane, ws)) {
@@ -245,23 +249,24 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
         return;
     }
     if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, Z, R)], L.slot[coop_pick(g, H, H, R)], k);
-    if (g == 0) coop_put(L, HH, k, r);
+    if (g == 0) L.slot[HH][k] = r;                          // HH, W: first operands / tail operands only
     else if (g == 1) coop_put(L, Z, k, r);
-    else if (g == 2) coop_put(L, W, k, r);
+    else if (g == 2) L.slot[W][k] = r;
     coop_sync();
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, H, X)], L.slot[HH], k);
+    pre = L.slot[W][k];
+    if (g < 2) r = coop_group_mul(L.slot[HH], L.slot[coop_pick(g, H, X)], k);
     {
         const u64 hhh = __shfl(r, (int)k);              // group 0's product, seen by every group
         if (g == 0) {
-            coop_put(L, HHH, k, r);
+            L.slot[HHH][k] = r;
         } else if (g == 1) {
-            const u64 x3 = fp_sub(fp_sub(L.slot[W][k], hhh), fp_dbl(r));
+            const u64 x3 = fp_sub(fp_sub(pre, hhh), fp_dbl(r));
             coop_put(L, X, k, x3);
-            coop_put(L, D, k, fp_sub(r, x3));
+            L.slot[D][k] = fp_sub(r, x3);
         }
     }
     coop_sync();
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, R, Y)], L.slot[coop_pick(g, D, HHH)], k);
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, D, HHH)], L.slot[coop_pick(g, R, Y)], k);
     {
         const u64 yh = __shfl(r, (int)(6u + k));        // group 1's product
         if (g == 0) coop_put(L, Y, k, fp_sub(r, yh));
