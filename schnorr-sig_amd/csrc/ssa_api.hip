@@ -548,6 +548,27 @@ extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const ui
 extern "C" int ssa_bench_fpmul(ssa_ctx *ctx, int variant, double *fpmul_per_s) {
     if (!ctx || !fpmul_per_s) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (variant >= 10 && variant <= 12) {   // cooperative point-operation chain: result = operations per second
+        if (ctx->st_aux.reserve(64)) return SSA_ERR_HIP;
+        hipEvent_t c0, c1;
+        HIP_TRY(hipEventCreate(&c0));
+        HIP_TRY(hipEventCreate(&c1));
+        const int n_ops = 2000;
+        for (int rep = 0; rep < 2; rep++) {
+            HIP_TRY(hipEventRecord(c0, ctx->stream));
+            hipLaunchKernelGGL(ssa_k_coop_bench, dim3(1), dim3(64), 0, ctx->stream, variant - 10, n_ops,
+                               (u64 *)ctx->st_aux.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c1, ctx->stream));
+            HIP_TRY(hipEventSynchronize(c1));
+        }
+        float cms = 0;
+        HIP_TRY(hipEventElapsedTime(&cms, c0, c1));
+        (void)hipEventDestroy(c0);
+        (void)hipEventDestroy(c1);
+        *fpmul_per_s = n_ops / (cms * 1e-3);
+        return 0;
+    }
     const unsigned blocks = 256 * 16, threads = 256;
     const int iters = 2000;
     if (ctx->st_aux.reserve((size_t)blocks * threads * 8)) return SSA_ERR_HIP;

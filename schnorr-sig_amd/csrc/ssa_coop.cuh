@@ -145,21 +145,43 @@ COOP_FN void coop_inv(CoopLds &L, int dst, int a, int t0, int t1, int t2, u32 la
 // (lazy accumulation, one reduction -- the arithmetic of the per-lane kernels), then the group applies the
 // additions that follow the product in the formula and stores the value -- with its 7x half (coop_put) when
 // the value will be the SECOND operand of a later product, which is the one read through the wrapped terms.
-COOP_FN u64 coop_group_mul(const u64 *A, const u64 *B, u32 k) {
-    u64 x[6], y[6];
+// COOP_LPC lanes share a coefficient (terms i = q, q + COOP_LPC, ...): shorter multiply chains per lane; the
+// partial results meet through a DPP swap of neighbouring lanes.  Lane layout: lane = COOP_LPC * (6 g + k) + q.
+#ifndef COOP_LPC
+#define COOP_LPC 2
+#endif
+COOP_FN u64 coop_swap_neighbour(u64 v) {   // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)lo32(v), 0xB1, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)hi32(v), 0xB1, 0xf, 0xf, false);
+    return mk64((u32)lo, (u32)hi);
+}
+COOP_FN u64 coop_group_mul(const u64 *A, const u64 *B, u32 k, u32 q) {
+    constexpr int NT = 6 / COOP_LPC;
+    u64 x[NT], y[NT];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int j = 0; j < NT; j++) {
+        const int i = (int)q + COOP_LPC * j;
         int idx = (int)k - i;          // b_{k-i}, or 7 b_{k-i+6} from the upper half
         if (idx < 0) idx += 12;
-        x[i] = A[i];
-        y[i] = B[idx];
+        x[j] = A[i];
+        y[j] = B[idx];
     }
     fp_acc acc;
     acc_init(acc, x[0], y[0]);
 #pragma unroll
-    for (int i = 1; i < 6; i++) acc_mac(acc, x[i], y[i]);
-    return acc_reduce(acc);
+    for (int j = 1; j < NT; j++) acc_mac(acc, x[j], y[j]);
+    u64 r = acc_reduce(acc);
+#if COOP_LPC == 2
+    r = fp_add(r, coop_swap_neighbour(r));
+#endif
+    return r;
 }
+// lane -> (group g, coefficient k, sub-lane q)
+#define COOP_LANE_ROLES(lane)                                              \
+    const u32 q = (lane) % (u32)COOP_LPC, hl_ = (lane) / (u32)COOP_LPC;    \
+    const u32 g = hl_ / 6u, k = hl_ - 6u * g
+// lane holding coefficient k of group g (source of a cross-group shuffle)
+COOP_FN int coop_lane_of(u32 g, u32 k) { return (int)((6u * g + k) * (u32)COOP_LPC); }
 COOP_FN void coop_put(CoopLds &L, int dst, u32 k, u64 r) {
     L.slot[dst][k] = r;
     L.slot[dst][6 + k] = fp_mul_small(r, 7u);
@@ -180,31 +202,32 @@ COOP_FN int coop_pick(u32 g, int s0, int s1, int s2 = 0, int s3 = 0) {
 // another group's tail writes.
 COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lane, int ws = 0) {
     const int YY = t[0], ZZ = t[1], M = t[2], E = t[3], S = t[4], W = t[5];
-    const u32 g = lane / 6u, k = lane - 6u * g;
+    COOP_LANE_ROLES(lane);
+    (void)q;
     u64 r = 0;
-    if (g < 4) r = coop_group_mul(L.slot[coop_pick(g, X, Y, Z, Y)], L.slot[coop_pick(g, X, Y, Z, Z)], k);
+    if (g < 4) r = coop_group_mul(L.slot[coop_pick(g, X, Y, Z, Y)], L.slot[coop_pick(g, X, Y, Z, Z)], k, q);
     if (g == 0) L.slot[M][k] = fp_add(fp_dbl(r), r);          // M3: a tail operand only, no 7x half
     else if (g == 1) coop_put(L, YY, k, r);
     else if (g == 2) coop_put(L, ZZ, k, r);
     else if (g == 3) coop_put(L, Z, k, fp_dbl(r));
     coop_sync();
     u64 pre = L.slot[M][k];     // tail operands are fetched before the products: their LDS latency hides
-    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, YY, X, ZZ)], L.slot[coop_pick(g, YY, YY, ZZ)], k);
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, YY, X, ZZ)], L.slot[coop_pick(g, YY, YY, ZZ)], k, q);
     if (g == 0) L.slot[E][k] = fp_dbl(fp_dbl(fp_dbl(r)));        // E, S: read by tails only, no 7x half
     else if (g == 1) L.slot[S][k] = fp_dbl(fp_dbl(r));
     else if (g == 2) coop_put(L, M, k, fp_add(r, pre));
     coop_sync();
     if (g == 0) {
         pre = L.slot[S][k];
-        r = coop_group_mul(L.slot[M], L.slot[M], k);
+        r = coop_group_mul(L.slot[M], L.slot[M], k, q);
         const u64 x3 = fp_sub(r, fp_dbl(pre));
         coop_put(L, X, k, x3);
-        L.slot[W][k] = fp_sub(pre, x3);     // W is only ever a first operand: no 7x half needed
+        L.slot[W][k] = fp_sub(pre, x3);     // W is the FIRST operand of R4: no 7x half needed
     }
     coop_sync();
     if (g == 0) {
         pre = L.slot[E][k];
-        r = coop_group_mul(L.slot[M], L.slot[W], k);
+        r = coop_group_mul(L.slot[W], L.slot[M], k, q);
         coop_put(L, Y, k, fp_sub(r, pre));
     }
     coop_sync();
@@ -219,7 +242,8 @@ COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lan
 //   R5  R D | Y HHH -> Y3 = R D - Y HHH
 COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, const int *t, u32 lane, int ws = 0) {
     const int Z1Z1 = t[0], QYZ = t[1], H = t[2], R = t[3], HH = t[4], W = t[5], HHH = t[6], D = t[7];
-    const u32 g = lane / 6u, k = lane - 6u * g;
+    COOP_LANE_ROLES(lane);
+    (void)q;
     const bool p_inf = coop_is_zero(L, Z, lane, ws);
     const bool q_inf = coop_is_zero(L, QX, lane, ws) && coop_is_zero(L, QY, lane, ws);
     if (q_inf) return;
@@ -231,12 +255,12 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
         return;
     }
     u64 r = 0;
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, Z, QY)], L.slot[Z], k);
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, Z, QY)], L.slot[Z], k, q);
     if (g == 0) coop_put(L, Z1Z1, k, r);
     else if (g == 1) L.slot[QYZ][k] = r;                    // only ever a first operand: no 7x half
     coop_sync();
     u64 pre = L.slot[coop_pick(g, X, Y)][k];
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, QX, QYZ)], L.slot[Z1Z1], k);
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, QX, QYZ)], L.slot[Z1Z1], k, q);
     if (g == 0) coop_put(L, H, k, fp_sub(r, pre));
     else if (g == 1) coop_put(L, R, k, fp_sub(r, pre));
     coop_sync();
@@ -248,15 +272,15 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
         }
         return;
     }
-    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, Z, R)], L.slot[coop_pick(g, H, H, R)], k);
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, Z, R)], L.slot[coop_pick(g, H, H, R)], k, q);
     if (g == 0) L.slot[HH][k] = r;                          // HH, W: first operands / tail operands only
     else if (g == 1) coop_put(L, Z, k, r);
     else if (g == 2) L.slot[W][k] = r;
     coop_sync();
     pre = L.slot[W][k];
-    if (g < 2) r = coop_group_mul(L.slot[HH], L.slot[coop_pick(g, H, X)], k);
+    if (g < 2) r = coop_group_mul(L.slot[HH], L.slot[coop_pick(g, H, X)], k, q);
     {
-        const u64 hhh = __shfl(r, (int)k);              // group 0's product, seen by every group
+        const u64 hhh = __shfl(r, coop_lane_of(0, k));  // group 0's product, seen by every group
         if (g == 0) {
             L.slot[HHH][k] = r;
         } else if (g == 1) {
@@ -266,9 +290,9 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
         }
     }
     coop_sync();
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, D, HHH)], L.slot[coop_pick(g, R, Y)], k);
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, D, HHH)], L.slot[coop_pick(g, R, Y)], k, q);
     {
-        const u64 yh = __shfl(r, (int)(6u + k));        // group 1's product
+        const u64 yh = __shfl(r, coop_lane_of(1, k));   // group 1's product
         if (g == 0) coop_put(L, Y, k, fp_sub(r, yh));
     }
     coop_sync();
@@ -285,7 +309,8 @@ COOP_FN void coop_jac_add(CoopLds &L, int X1, int Y1, int Z1, int X2, int Y2, in
                           int ws = 0) {
     const int A = t[0], B = t[1], C = t[2], Dd = t[3], E = t[4], U1 = t[5], S1 = t[6], H = t[7], R = t[8];
     const int HH = t[0], W = t[1], HHH = t[2], F = t[3];
-    const u32 g = lane / 6u, k = lane - 6u * g;
+    COOP_LANE_ROLES(lane);
+    (void)q;
     if (coop_is_zero(L, Z2, lane, ws)) return;
     if (coop_is_zero(L, Z1, lane, ws)) {
         if (g == 0) coop_put(L, X1, k, L.slot[X2][k]);
@@ -298,13 +323,13 @@ COOP_FN void coop_jac_add(CoopLds &L, int X1, int Y1, int Z1, int X2, int Y2, in
     if (g < 5) {
         const int sa = g == 0 ? Z1 : (g == 1 ? Z2 : (g == 2 ? Y1 : (g == 3 ? Y2 : Z1)));
         const int sb = g == 0 ? Z1 : (g == 1 ? Z2 : (g == 2 ? Z2 : (g == 3 ? Z1 : Z2)));
-        r = coop_group_mul(L.slot[sa], L.slot[sb], k);
+        r = coop_group_mul(L.slot[sa], L.slot[sb], k, q);
         coop_put(L, g == 0 ? A : (g == 1 ? B : (g == 2 ? C : (g == 3 ? Dd : E))), k, r);
     }
     coop_sync();
-    if (g < 4) r = coop_group_mul(L.slot[coop_pick(g, X1, X2, C, Dd)], L.slot[coop_pick(g, B, A, B, A)], k);
+    if (g < 4) r = coop_group_mul(L.slot[coop_pick(g, X1, X2, C, Dd)], L.slot[coop_pick(g, B, A, B, A)], k, q);
     {
-        const u64 u1 = __shfl(r, (int)k), s1 = __shfl(r, (int)(12u + k));
+        const u64 u1 = __shfl(r, coop_lane_of(0, k)), s1 = __shfl(r, coop_lane_of(2, k));
         if (g == 0) coop_put(L, U1, k, r);
         else if (g == 1) coop_put(L, H, k, fp_sub(r, u1));
         else if (g == 2) coop_put(L, S1, k, r);
@@ -319,14 +344,14 @@ COOP_FN void coop_jac_add(CoopLds &L, int X1, int Y1, int Z1, int X2, int Y2, in
         }
         return;
     }
-    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, E, R)], L.slot[coop_pick(g, H, H, R)], k);
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, E, R)], L.slot[coop_pick(g, H, H, R)], k, q);
     if (g == 0) coop_put(L, HH, k, r);
     else if (g == 1) coop_put(L, Z1, k, r);
     else if (g == 2) coop_put(L, W, k, r);
     coop_sync();
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, H, U1)], L.slot[HH], k);
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, H, U1)], L.slot[HH], k, q);
     {
-        const u64 hhh = __shfl(r, (int)k);
+        const u64 hhh = __shfl(r, coop_lane_of(0, k));
         if (g == 0) {
             coop_put(L, HHH, k, r);
         } else if (g == 1) {
@@ -336,9 +361,9 @@ COOP_FN void coop_jac_add(CoopLds &L, int X1, int Y1, int Z1, int X2, int Y2, in
         }
     }
     coop_sync();
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, R, S1)], L.slot[coop_pick(g, F, HHH)], k);
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, R, S1)], L.slot[coop_pick(g, F, HHH)], k, q);
     {
-        const u64 sh = __shfl(r, (int)(6u + k));
+        const u64 sh = __shfl(r, coop_lane_of(1, k));
         if (g == 0) coop_put(L, Y1, k, fp_sub(r, sh));
     }
     coop_sync();

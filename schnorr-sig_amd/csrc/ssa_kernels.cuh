@@ -740,6 +740,26 @@ ssa_k_verify_coop(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs
         if (st != ST_OK) atomicAdd(n_fail, 1ull);
     }
 }
+// probe: a chain of dependent cooperative point operations on ONE wave (op 0: doubling, 1: mixed addition,
+// 2: general addition); the latency the low-latency kernel and the MSM tail are made of
+__global__ void __launch_bounds__(64) ssa_k_coop_bench(int op, int iters, u64 *out) {
+    __shared__ CoopLds L;
+    const u32 lane = threadIdx.x;
+    int t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = 8 + k;
+    for (int s0 = 0; s0 < 8; s0++) {
+        coop_store7(L, s0, 0x9e3779b97f4a7c15ULL * (u64)(7 * s0 + (int)(lane % 6u) + 1), lane);
+    }
+    coop_sync();
+#pragma unroll 1
+    for (int i = 0; i < iters; i++) {
+        if (op == 0) coop_jac_dbl(L, 0, 1, 2, t, lane);
+        else if (op == 1) coop_jac_madd(L, 0, 1, 2, 3, 4, t, lane);
+        else coop_jac_add(L, 0, 1, 2, 3, 4, 5, t, lane);
+    }
+    if (lane < 6) out[lane] = L.slot[0][lane] ^ L.slot[1][lane] ^ L.slot[2][lane];
+}
 }  // namespace ssa
 #endif  // SSA_NO_KERNELS
 #endif  // SSA_NO_COOP
