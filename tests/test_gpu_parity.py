@@ -874,7 +874,7 @@ def test_both_kernel_families_on_the_edge_cases(engine, oracle, mode):
 def test_auto_dispatch_agrees_across_the_threshold(engine):
     """auto mode switches kernel family at the context's threshold; verdicts must not depend on it."""
     rng = np.random.default_rng(62)
-    n = 12000
+    n = 15000
     sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
     msgs = rng.integers(0, 256, size=(n, 33), dtype=np.uint8)
     pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
@@ -882,7 +882,7 @@ def test_auto_dispatch_agrees_across_the_threshold(engine):
     sigs[bad, 52] ^= 4
     expect = np.zeros(n, dtype=np.uint8)
     expect[bad] = 2
-    for torsion, cuts in ((True, (1, 100, 8192, 8193, n)), (False, (5632, 5633))):
+    for torsion, cuts in ((True, (1, 100, 14336, 14337, n)), (False, (10240, 10241))):
         for cut in cuts:
             st, nf = engine.verify_many(sigs[:cut], pks[:cut], msgs[:cut], check_torsion=torsion)
             assert (st == expect[:cut]).all() and nf == int((expect[:cut] != 0).sum())
