@@ -119,7 +119,8 @@ int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, cons
 /* verify_batch exactly as src/batch.rs:31-130: sum s_i R_i - sum (s_i h_i) P_i ?= [sum s_i e_i] G with
  * R_i decompressed from sig.x (flag byte honoured), a 2n-point bucket MSM on the GPU and an x-only
  * comparison.  coeffs: n x 32-byte scalars standing in for Scalar::random(rng) (reduced mod q), or
- * NULL for 128-bit coefficients drawn from getrandom(2).  Returns SSA_OK, SSA_INVALID_SIGNATURE, or
+ * NULL for 128-bit coefficients from a ChaCha20 stream (RFC 8439) generated on the device and keyed per
+ * call with getrandom(2).  Returns SSA_OK, SSA_INVALID_SIGNATURE, or
  * SSA_MALFORMED where the reference panics (undecodable sig.x, src/batch.rs:67,104).  No torsion
  * check, like the reference.  n <= 2^25 per call. */
 int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
@@ -175,7 +176,8 @@ int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_
                                 uint8_t *d_sigs_out);
 int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t n, uint8_t *d_pks_out,
                                uint8_t *d_pk_inf_out, uint8_t *d_status_out);
-/* coeff_bytes in 1..32: little-endian coefficient width; *d_verdict_out receives the status */
+/* coeff_bytes in 1..32: little-endian coefficient width (d_coeffs == NULL: the library draws 128-bit
+ * coefficients as above); *d_verdict_out receives the status */
 int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
                                 const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
                                 size_t msg_len, size_t n, const uint8_t *d_coeffs, uint32_t coeff_bytes,
@@ -198,7 +200,11 @@ int ssa_multi_verify_many(ssa_multi *m, const uint8_t *sigs, const uint8_t *pks,
  *     4 = scalar mul [k]P (k in a[0..4], P in b), 5 = Fp mul (a[0]*b[0]), 6 = Fp inv */
 int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                     size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride);
-/* register-resident Fp-mul throughput probe: returns Fp multiplications per second */
+/* n_blocks 64-byte blocks of the ChaCha20 keystream the MSM coefficients come from (RFC 8439 known answers) */
+int ssa_debug_chacha20(ssa_ctx *ctx, const uint8_t key[32], const uint8_t nonce[12], uint32_t counter0,
+                       size_t n_blocks, uint8_t *out);
+/* register-resident Fp-mul throughput probe: returns Fp multiplications per second; variants 10..12: dependent
+ * cooperative doublings / mixed additions / general additions per second (one wave) */
 int ssa_bench_fpmul(ssa_ctx *ctx, int variant, double *fpmul_per_s);
 
 #ifdef __cplusplus

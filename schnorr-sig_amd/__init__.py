@@ -98,6 +98,7 @@ def _load():
         "ssa_decompress_many_device": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_debug_arith": (i32, [vp, i32, vp, vp, sz, sz, sz, vp, sz]),
         "ssa_bench_fpmul": (i32, [vp, i32, C.POINTER(C.c_double)]),
+        "ssa_debug_chacha20": (i32, [vp, vp, vp, u32, sz, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here == ABI symbol missing: fail loudly
@@ -213,6 +214,15 @@ class Engine:
         _check(_lib.ssa_verify_batch_msm_device(self._ctx, d_sigs, d_pks, d_msgs, d_offsets or None,
                                                 msg_stride if msg_stride is not None else msg_len, msg_len, n,
                                                 d_coeffs, coeff_bytes, d_verdict), "ssa_verify_batch_msm_device")
+
+    def debug_chacha20(self, key32, nonce12, counter0, n_blocks):
+        """keystream blocks of the generator the MSM coefficients come from (RFC 8439 block function)"""
+        key, nonce = _np_u8(bytearray(key32)), _np_u8(bytearray(nonce12))
+        assert key.size == 32 and nonce.size == 12
+        out = np.zeros(64 * n_blocks, dtype=np.uint8)
+        _check(_lib.ssa_debug_chacha20(self._ctx, _ptr(key), _ptr(nonce), C.c_uint32(counter0), C.c_size_t(n_blocks),
+                                       _ptr(out)), "ssa_debug_chacha20")
+        return out.tobytes()
 
     def verify_one(self, sig81, pk96, message, check_torsion=True):
         sig, pk = _np_u8(bytearray(sig81)), _np_u8(bytearray(pk96))

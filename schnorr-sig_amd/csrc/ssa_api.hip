@@ -198,6 +198,10 @@ int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t
     });
 }
 
+static int verify_launch(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                         const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                         uint32_t flags, uint8_t *d_status_out, unsigned long long *d_fail);
+
 extern "C" int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
                                       const uint8_t *d_pk_inf, const uint8_t *d_msgs,
                                       const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len,
@@ -210,6 +214,14 @@ extern "C" int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const
                                               : (unsigned long long *)ctx->ws_fail.p;
     HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), ctx->stream));
     if (n == 0) return 0;
+    return verify_launch(ctx, d_sigs, d_pks, d_pk_inf, d_msgs, d_msg_off, msg_stride, msg_len, n, flags, d_status_out,
+                         d_fail);
+}
+
+// the kernels of one verification batch on ctx->stream; *d_fail is added to, not reset
+static int verify_launch(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                         const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                         uint32_t flags, uint8_t *d_status_out, unsigned long long *d_fail) {
     MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
     // small batches: one wave per signature (low latency); large ones: one lane per signature (throughput)
     const size_t coop_lim = (flags & SSA_FLAG_CHECK_TORSION) ? ctx->coop_max_n_torsion : ctx->coop_max_n;

@@ -208,6 +208,44 @@ msm_k_tree(const u64 *__restrict__ in, u32 windows, u32 count, u32 group, u64 *_
     st_jac(out + 18 * (size_t)t, acc);
 }
 
+// ---- coefficients ---------------------------------------------------------------------------------
+// Scalar::random(rng) (src/batch.rs:75-78) when the caller supplies none: 128-bit coefficients from a
+// ChaCha20 keystream (RFC 8439 block function, 32-bit block counter) keyed per call with 44 bytes of
+// getrandom(2).  One 64-byte block = four coefficients per lane; drawing 16 MB on the host took ~20 ms.
+struct ChaChaKey {
+    u32 key[8];
+    u32 nonce[3];
+};
+SSA_DEV u32 rotl32(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+#define SSA_QR(a, b, c, d)          \
+    a += b; d ^= a; d = rotl32(d, 16); \
+    c += d; b ^= c; b = rotl32(b, 12); \
+    a += b; d ^= a; d = rotl32(d, 8);  \
+    c += d; b ^= c; b = rotl32(b, 7)
+__global__ void __launch_bounds__(256)
+msm_k_chacha20(ChaChaKey kn, u32 counter0, size_t n_blocks, u32 *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_blocks) return;
+    u32 st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, kn.key[0], kn.key[1], kn.key[2], kn.key[3],
+                  kn.key[4], kn.key[5], kn.key[6], kn.key[7], counter0 + (u32)t, kn.nonce[0], kn.nonce[1], kn.nonce[2]};
+    u32 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = st[i];
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {
+        SSA_QR(x[0], x[4], x[8], x[12]);
+        SSA_QR(x[1], x[5], x[9], x[13]);
+        SSA_QR(x[2], x[6], x[10], x[14]);
+        SSA_QR(x[3], x[7], x[11], x[15]);
+        SSA_QR(x[0], x[5], x[10], x[15]);
+        SSA_QR(x[1], x[6], x[11], x[12]);
+        SSA_QR(x[2], x[7], x[8], x[13]);
+        SSA_QR(x[3], x[4], x[9], x[14]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[16 * t + i] = x[i] + st[i];   // little-endian words = the keystream bytes
+}
+
 // ---- the one sequential chain of the reduction ---------------------------------------------------
 // left = sum_j 2^(c j) W_j by Horner's rule: (windows - 1) x (c doublings + one addition), a chain of ~240
 // dependent doublings.  A lone lane ran it at ~80 us per doubling; here wave 0 of the block works on the
@@ -330,19 +368,65 @@ static MsmShape msm_shape(size_t n) {
     return sh;
 }
 
+// n_blocks 64-byte ChaCha20 blocks into d_out (device), on the context's stream
+static int msm_chacha20(ssa_ctx *ctx, const uint8_t key[32], const uint8_t nonce[12], uint32_t counter0,
+                        size_t n_blocks, void *d_out) {
+    ChaChaKey kn;
+    memcpy(kn.key, key, 32);
+    memcpy(kn.nonce, nonce, 12);
+    if (n_blocks == 0) return 0;
+    hipLaunchKernelGGL(msm_k_chacha20, dim3(grid_for(n_blocks, 256)), dim3(256), 0, ctx->stream, kn, counter0, n_blocks,
+                       (u32 *)d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// fresh 128-bit coefficients for n signatures in ctx->st_coeffs (device)
+static int msm_draw_coefficients(ssa_ctx *ctx, size_t n, const void **d_out) {
+    uint8_t seed[44];
+    size_t got = 0;
+    while (got < sizeof seed) {
+        ssize_t r = getrandom(seed + got, sizeof seed - got, 0);
+        if (r <= 0) return SSA_ERR_ARG;
+        got += (size_t)r;
+    }
+    const size_t n_blocks = (n * 16 + 63) / 64;
+    if (ctx->st_coeffs.reserve(n_blocks * 64)) return SSA_ERR_HIP;
+    if (int rc = msm_chacha20(ctx, seed, seed + 32, 0u, n_blocks, ctx->st_coeffs.p)) return rc;
+    *d_out = ctx->st_coeffs.p;
+    return 0;
+}
+
+extern "C" int ssa_debug_chacha20(ssa_ctx *ctx, const uint8_t key[32], const uint8_t nonce[12], uint32_t counter0,
+                                  size_t n_blocks, uint8_t *out) {
+    if (!ctx || !key || !nonce || (n_blocks && !out)) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->st_coeffs.reserve(n_blocks * 64 + 64)) return SSA_ERR_HIP;
+    if (int rc = msm_chacha20(ctx, key, nonce, counter0, n_blocks, ctx->st_coeffs.p)) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->st_coeffs.p, n_blocks * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
                                            const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
                                            size_t msg_len, size_t n, const uint8_t *d_coeffs, uint32_t coeff_bytes,
                                            uint32_t *d_verdict_out) {
     if (!ctx || !d_verdict_out) return SSA_ERR_ARG;
-    if (n && (!d_sigs || !d_pks || !d_coeffs)) return SSA_ERR_ARG;
-    if (coeff_bytes == 0 || coeff_bytes > 32) return SSA_ERR_ARG;
+    if (n && (!d_sigs || !d_pks)) return SSA_ERR_ARG;
+    if (d_coeffs && (coeff_bytes == 0 || coeff_bytes > 32)) return SSA_ERR_ARG;
     if (n > (1ull << 25)) return SSA_ERR_ARG;   // 2n * 16 sort items must fit hipCUB's int item count
     if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     if (n == 0) {   // empty batch: Ok (src/batch.rs)
         HIP_TRY(hipMemsetAsync(d_verdict_out, 0, sizeof(uint32_t), ctx->stream));
         return 0;
+    }
+    if (!d_coeffs) {   // Scalar::random(rng): the library draws 128-bit coefficients
+        const void *p;
+        if (int rc = msm_draw_coefficients(ctx, n, &p)) return rc;
+        d_coeffs = (const uint8_t *)p;
+        coeff_bytes = 16;
     }
     const MsmShape sh = msm_shape(n);
     const size_t npts = 2 * n, total = npts * sh.windows, nb = (size_t)sh.windows * sh.buckets;
@@ -416,21 +500,8 @@ extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uin
     if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
     if (n == 0) return SSA_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    // Scalar::random(rng) (src/batch.rs:75-78): caller-supplied 32-byte scalars, or 128-bit
-    // coefficients from the kernel's CSPRNG (getrandom) when coeffs == NULL
-    std::vector<uint8_t> own;
-    uint32_t cb = 32;
-    if (!coeffs) {
-        cb = 16;
-        own.resize(n * 16);
-        size_t got = 0;
-        while (got < own.size()) {
-            ssize_t r = getrandom(own.data() + got, own.size() - got, 0);
-            if (r <= 0) return SSA_ERR_ARG;
-            got += (size_t)r;
-        }
-        coeffs = own.data();
-    }
+    // Scalar::random(rng) (src/batch.rs:75-78): caller-supplied 32-byte scalars, or (coeffs == NULL) 128-bit
+    // coefficients drawn on the device from a ChaCha20 stream keyed with getrandom(2)
     StagedInputs s;
     const void *p;
     if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;
@@ -438,10 +509,13 @@ extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uin
     if (int rc = stage_up(ctx, ctx->st_pks, pks, n * 96, &p)) return rc;
     s.pks = (const u8 *)p;
     if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
-    if (int rc = stage_up(ctx, ctx->st_coeffs, coeffs, n * cb, &p)) return rc;
+    p = nullptr;
+    if (coeffs) {
+        if (int rc = stage_up(ctx, ctx->st_coeffs, coeffs, n * 32, &p)) return rc;
+    }
     uint32_t *d_verdict = (uint32_t *)((char *)ctx->ws_fail.p + 32);
     if (int rc = ssa_verify_batch_msm_device(ctx, s.sigs, s.pks, s.msgs, s.off, msg_stride, msg_len, n,
-                                             (const u8 *)p, cb, d_verdict))
+                                             (const u8 *)p, 32, d_verdict))
         return rc;
     uint32_t v = SSA_MALFORMED;
     HIP_TRY(hipMemcpyAsync(&v, d_verdict, sizeof v, hipMemcpyDeviceToHost, ctx->stream));

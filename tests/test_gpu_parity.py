@@ -886,3 +886,59 @@ def test_auto_dispatch_agrees_across_the_threshold(engine):
         for cut in cuts:
             st, nf = engine.verify_many(sigs[:cut], pks[:cut], msgs[:cut], check_torsion=torsion)
             assert (st == expect[:cut]).all() and nf == int((expect[:cut] != 0).sum())
+
+
+# ---- coefficients of the MSM-form verify_batch: ChaCha20 keystream generated on the device ------------------
+def _chacha20_block(key, counter, nonce):
+    """RFC 8439 section 2.3, straight from the text (independent of the kernel)."""
+    import struct
+    def rotl(x, n):
+        return ((x << n) | (x >> (32 - n))) & 0xffffffff
+    def qr(x, a, b, c, d):
+        x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 7)
+    st = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + list(struct.unpack("<8I", key)) + [counter] + \
+        list(struct.unpack("<3I", nonce))
+    x = list(st)
+    for _ in range(10):
+        qr(x, 0, 4, 8, 12); qr(x, 1, 5, 9, 13); qr(x, 2, 6, 10, 14); qr(x, 3, 7, 11, 15)
+        qr(x, 0, 5, 10, 15); qr(x, 1, 6, 11, 12); qr(x, 2, 7, 8, 13); qr(x, 3, 4, 9, 14)
+    return struct.pack("<16I", *[(a + b) & 0xffffffff for a, b in zip(x, st)])
+
+
+RFC8439_KEY = bytes(range(32))
+RFC8439_NONCE = bytes.fromhex("000000090000004a00000000")
+RFC8439_BLOCK1 = bytes.fromhex(
+    "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+    "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+
+
+def test_chacha20_model_reproduces_rfc8439_block():
+    assert _chacha20_block(RFC8439_KEY, 1, RFC8439_NONCE) == RFC8439_BLOCK1      # RFC 8439 section 2.3.2
+
+
+def test_device_chacha20_keystream(engine):
+    """the generator behind `coeffs=None`: RFC 8439 known answer and random keys against the Python model"""
+    assert engine.debug_chacha20(RFC8439_KEY, RFC8439_NONCE, 1, 1) == RFC8439_BLOCK1
+    rng = np.random.default_rng(77)
+    for _ in range(3):
+        key, nonce = rng.bytes(32), rng.bytes(12)
+        got = engine.debug_chacha20(key, nonce, 5, 300)
+        want = b"".join(_chacha20_block(key, 5 + i, nonce) for i in range(300))
+        assert got == want
+
+
+def test_msm_form_with_library_drawn_coefficients(engine):
+    """coeffs=None: fresh device-drawn coefficients every call; the verdict does not depend on them"""
+    rng = np.random.default_rng(78)
+    n = 5000
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, 21), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    for _ in range(3):
+        assert engine.verify_batch_msm(sigs, pks, msgs) == 0
+    sigs[1234, 60] ^= 1
+    for _ in range(3):
+        assert engine.verify_batch_msm(sigs, pks, msgs) == 2
