@@ -210,7 +210,7 @@ def main():
         achieved = w_kernel * n / (k_verify_ms * 1e-3) if k_verify_ms > 0 else 0.0
         traffic, valu_util = None, None   # from the committed PMC passes of the same workload (profiles/r01)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_v4.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_v5.json")) as fh:
                 if n == 1 << 20:
                     pmc = json.load(fh)["ssa_k_verify"]
                     traffic, valu_util = pmc["hbm_bytes_per_launch"], pmc["valu_issue_utilisation"]

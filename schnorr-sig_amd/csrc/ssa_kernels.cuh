@@ -10,9 +10,9 @@
 // HBM layout: inputs stay in the caller's AoS byte records (81-B signatures, 96-B keys,
 // message bytes); per-lane intermediates live in the context workspace:
 //   ws_h    n x 4 u64       challenge scalars
-//   ws_tab  n x 8 x 24 u64  per-lane affine multiples 1P..8P (96 B used per 192-B row; the rest is
-//                           scratch of the batch normalisation), lane-contiguous so that a lane's
-//                           gather of one entry is six 16-byte loads from one row
+//   ws_tab  n x 8 x 32 u64  per-lane affine multiples 1P..8P (256-B rows: x, y in the first 128-B line, the
+//                           scratch of the batch normalisation in the second), lane-contiguous so that a
+//                           lane's gather of one entry is six 16-byte loads from one cache line
 //   gtab    16 x 65536 x 12 u64 affine multiples d*2^(16w)*G (100 MB, Infinity-Cache resident)
 #pragma once
 #include "curve.cuh"
@@ -25,7 +25,9 @@ constexpr int GW_BITS = 16;
 constexpr int GW_COUNT = 16;
 constexpr size_t GTAB_ENTRIES = (size_t)GW_COUNT << GW_BITS;
 constexpr int PTAB_ENTRIES = 8;
-constexpr int PTAB_ENTRY_U64 = 24;  // X, Y, Z, prefix product while building; affine x, y after
+// a table row is 256 B = two 128-B lines: X, Y (affine x, y after the build) in the first -- a gather of the
+// ladder touches exactly one line -- and Z, prefix product of the build in the second
+constexpr int PTAB_ENTRY_U64 = 32, PTAB_Z = 16, PTAB_C = 22;
 
 constexpr u32 ST_OK = 0, ST_INVALID_PK = 1, ST_INVALID_SIG = 2, ST_MALFORMED = 3;
 
@@ -220,10 +222,25 @@ SSA_DEV void st_aff(u64 *__restrict__ row, const aff &p) {
     st_f6(row + 6, p.y);
 }
 
+// a Jacobian point in a table row (X, Y in the first line, Z in the second); st_jac / ld_jac are the dense
+// 18-word records of the MSM buffers
+SSA_DEV void st_row(u64 *__restrict__ row, const jac &p) {
+    st_f6(row, p.X);
+    st_f6(row + 6, p.Y);
+    st_f6(row + PTAB_Z, p.Z);
+}
+SSA_DEV jac ld_row(const u64 *__restrict__ row) {
+    jac p;
+    p.X = ld_f6(row);
+    p.Y = ld_f6(row + 6);
+    p.Z = ld_f6(row + PTAB_Z);
+    return p;
+}
+
 // row-to-row point operations used only while building the table (cold code, kept out of line)
-SSA_FN void tab_dbl(u64 *__restrict__ dst, const u64 *__restrict__ src) { st_jac(dst, jac_dbl(ld_jac(src))); }
+SSA_FN void tab_dbl(u64 *__restrict__ dst, const u64 *__restrict__ src) { st_row(dst, jac_dbl(ld_row(src))); }
 SSA_FN void tab_madd(u64 *__restrict__ dst, const u64 *__restrict__ src, const u64 *__restrict__ paff) {
-    st_jac(dst, jac_madd(ld_jac(src), ld_aff(paff)));
+    st_row(dst, jac_madd(ld_row(src), ld_aff(paff)));
 }
 
 // Affine multiples 1P..8P of a lane's point into its table rows: 4 doublings + 3 mixed additions
@@ -240,7 +257,7 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
         for (int e = 0; e < PTAB_ENTRIES; e++) st_aff(tab + e * R, z);
         return;
     }
-    st_jac(tab, jac_from_aff(p));                 // row 0 doubles as affine P: (x, y, Z = 1)
+    st_row(tab, jac_from_aff(p));                 // row 0 doubles as affine P: (x, y, Z = 1)
     tab_dbl(tab + 1 * R, tab);                    // 2P
     tab_madd(tab + 2 * R, tab + 1 * R, tab);      // 3P = 2P + P
     tab_dbl(tab + 3 * R, tab + 1 * R);            // 4P
@@ -252,20 +269,20 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
     fp6 c = f6_one();
 #pragma unroll 1
     for (int e = 1; e < PTAB_ENTRIES; e++) {
-        fp6 z = ld_f6(tab + e * R + 12);
+        fp6 z = ld_f6(tab + e * R + PTAB_Z);
         if (f6_is_zero(z)) z = f6_one();
         c = f6_mul(c, z);
-        st_f6(tab + e * R + 18, c);
+        st_f6(tab + e * R + PTAB_C, c);
     }
     fp6 inv = f6_inv(c);
     // backward pass: 1/Z_e = inv * prefix_{e-1};  inv *= Z_e
 #pragma unroll 1
     for (int e = PTAB_ENTRIES - 1; e >= 1; e--) {
-        fp6 z = ld_f6(tab + e * R + 12);
+        fp6 z = ld_f6(tab + e * R + PTAB_Z);
         const bool zero = f6_is_zero(z);
         if (zero) z = f6_one();
         fp6 zinv = inv;
-        if (e > 1) zinv = f6_mul(inv, ld_f6(tab + (e - 1) * R + 18));
+        if (e > 1) zinv = f6_mul(inv, ld_f6(tab + (e - 1) * R + PTAB_C));
         inv = f6_mul(inv, z);
         const fp6 zi2 = f6_sqr(zinv);
         aff a;
