@@ -50,13 +50,16 @@ SSA_DEV u64 inv_sbox(u64 x) {
     return fp_mul(a, b);
 }
 
-// The 12-felt sponge state of a lane lives in LDS ("LDS-staged"): plane element i of lane t is
+// The 12-felt sponge state of a lane lives in LDS ("LDS-staged"): element i of lane t is
 // st[i * RS_STRIDE + t], so dynamic indexing costs a ds_read/ds_write instead of forcing the
 // whole permutation to be unrolled (17k instructions when it was register-resident; the
-// rolled form is ~2k and stays in the instruction cache).  Two planes ping-pong through the
-// MDS layers: 2 x 12 x 8 B = 192 B per lane, 48 KB per 256-thread block.
+// rolled form is ~2k and stays in the instruction cache).  ONE plane: the MDS layer loads the
+// whole state into registers before it writes the first output, so it runs in place.
+// 12 x 8 B = 96 B per lane, 24 KB per 256-thread block (two ping-pong planes: 48 KB, three blocks
+// per CU and 14.6 ms for ssa_k_hash at 2^20; one plane: five blocks, 14.1 ms -- the kernel is
+// VALU-bound, what the extra blocks buy is a shorter tail of the last block wave).
 constexpr int RS_STRIDE = 256;  // == blockDim.x of every kernel that hashes
-constexpr int RS_LDS_U64 = 2 * 12 * RS_STRIDE;
+constexpr int RS_LDS_U64 = 12 * RS_STRIDE;
 
 // dst <- MDS * src + ark (lazy 12-term accumulation per output, one reduction each).
 // SMALL: every MDS entry is below 2^32 (flag set by the host when it loads the blob), which

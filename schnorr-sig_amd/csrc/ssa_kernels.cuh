@@ -124,7 +124,7 @@ ssa_k_hash(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs,
            const u8 *__restrict__ pks, MsgView mv, size_t n, u64 *__restrict__ h_out,
            u8 *__restrict__ digest_out) {
     __shared__ u64 lds[RS_LDS_U64];
-    u64 *A = lds + threadIdx.x, *B = A + 12 * RS_STRIDE;
+    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.cuh)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool ok = true;
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256)
 ssa_k_rescue(const DevParams *__restrict__ prm, const u64 *__restrict__ felts, u32 per_row,
              size_t n, u64 *__restrict__ out) {
     __shared__ u64 lds[RS_LDS_U64];
-    u64 *A = lds + threadIdx.x, *B = A + 12 * RS_STRIDE;
+    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.cuh)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 *row = felts + (size_t)per_row * i;
@@ -501,7 +501,7 @@ ssa_k_sign(const DevParams *__restrict__ prm, const u64 *__restrict__ gtab,
            const u8 *__restrict__ sks, const u8 *__restrict__ nonces, MsgView mv, size_t n,
            u8 *__restrict__ pks_out, u8 *__restrict__ sigs_out) {
     __shared__ u64 lds[RS_LDS_U64];
-    u64 *A = lds + threadIdx.x, *B = A + 12 * RS_STRIDE;
+    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.cuh)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const sc256 sk = sc_reduce256(ld_sc(sks + 32 * i));
