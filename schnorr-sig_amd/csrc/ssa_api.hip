@@ -533,8 +533,8 @@ extern "C" int ssa_multi_verify_many(ssa_multi *m, const uint8_t *sigs, const ui
 // ------------------------------------------------------------------ probes
 extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                                size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {
-    if (!ctx || !a || !out || n == 0 || op < 0 || op > 6) return SSA_ERR_ARG;
-    if ((op == 0 || op == 3 || op == 4 || op == 5) && !b) return SSA_ERR_ARG;
+    if (!ctx || !a || !out || n == 0 || op < 0 || op > 7) return SSA_ERR_ARG;
+    if ((op == 0 || op == 3 || op == 4 || op == 5 || op == 7) && !b) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const void *da, *db = nullptr;
     if (int rc = stage_up(ctx, ctx->st_aux, a, n * a_stride * 8, &da)) return rc;
@@ -542,7 +542,10 @@ extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const ui
         if (int rc = stage_up(ctx, ctx->st_aux2, b, n * b_stride * 8, &db)) return rc;
     if (ctx->st_status.reserve(n * out_stride * 8)) return SSA_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->st_status.p, 0, n * out_stride * 8, ctx->stream));
-    if (op == 4) {
+    if (op == 7) {
+        hipLaunchKernelGGL(ssa_k_debug_coop, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const u64 *)da,
+                           (const u64 *)db, n, a_stride, b_stride, (u64 *)ctx->st_status.p, out_stride);
+    } else if (op == 4) {
         if (ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
         hipLaunchKernelGGL(ssa_k_debug_mul, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const u64 *)da,
                            (const u64 *)db, n, a_stride, b_stride, (u64 *)ctx->ws_tab.p,

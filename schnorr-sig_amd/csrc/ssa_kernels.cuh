@@ -757,6 +757,75 @@ ssa_k_verify_coop(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs
         if (st != ST_OK) atomicAdd(n_fail, 1ull);
     }
 }
+// unit probe of the cooperative point operations, one wave per row: a = (x, y, inf, mode), b = (x, y, inf);
+// mode 0: mixed addition a + b (a as a scaled Jacobian point, b affine), 1: general addition of two scaled
+// Jacobian points, 2: doubling of a.  out = affine (x, y, inf).
+__global__ void __launch_bounds__(64)
+ssa_k_debug_coop(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n, size_t as, size_t bs,
+                 u64 *__restrict__ out, size_t os) {
+    __shared__ CoopLds L;
+    const u32 lane = threadIdx.x;
+    const size_t i = blockIdx.x;
+    if (i >= n) return;
+    const u64 *pa = a + i * as, *pb = b + i * bs;
+    const int mode = (int)pa[13];
+    enum { X1 = 0, Y1, Z1, X2, Y2, Z2, LAM, T0, T1, T2, TS = 12 };
+    int t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = TS + k;
+    // Jacobian (lam^2 x, lam^3 y, lam) of an affine point, (1, 1, 0) for the identity
+    auto lift = [&](const u64 *p, int X, int Y, int Z, const u64 (&lam)[6]) {
+        if (p[12]) {
+            coop_set(L, X, 1ull, lane);
+            coop_set(L, Y, 1ull, lane);
+            coop_set(L, Z, 0ull, lane);
+            return;
+        }
+        coop_store7(L, X, p[lane % 6u], lane);
+        coop_store7(L, Y, p[6 + lane % 6u], lane);
+        coop_store7(L, LAM, lam[lane % 6u], lane);
+        coop_sync();
+        coop_copy(L, Z, LAM, lane);
+        coop_mul(L, T0, LAM, LAM, lane);
+        coop_mul(L, X, X, T0, lane);
+        coop_mul(L, T0, T0, LAM, lane);
+        coop_mul(L, Y, Y, T0, lane);
+    };
+    const u64 lam1[6] = {3, 1, 4, 1, 5, 9}, lam2[6] = {2, 7, 1, 8, 2, 8};
+    lift(pa, X1, Y1, Z1, lam1);
+    if (mode == 1) {
+        lift(pb, X2, Y2, Z2, lam2);
+        coop_jac_add(L, X1, Y1, Z1, X2, Y2, Z2, t, lane);
+    } else if (mode == 0) {
+        if (pb[12]) {
+            coop_set(L, X2, 0ull, lane);
+            coop_set(L, Y2, 0ull, lane);
+        } else {
+            coop_store7(L, X2, pb[lane % 6u], lane);
+            coop_store7(L, Y2, pb[6 + lane % 6u], lane);
+            coop_sync();
+        }
+        coop_jac_madd(L, X1, Y1, Z1, X2, Y2, t, lane);
+    } else {
+        coop_jac_dbl(L, X1, Y1, Z1, t, lane);
+    }
+    u64 *po = out + i * os;
+    if (coop_is_zero(L, Z1, lane)) {
+        if (lane == 0) po[12] = 1;
+        return;
+    }
+    coop_inv(L, T0, Z1, T1, T2, LAM, lane);
+    coop_mul(L, T1, T0, T0, lane);
+    coop_mul(L, X1, X1, T1, lane);
+    coop_mul(L, T1, T1, T0, lane);
+    coop_mul(L, Y1, Y1, T1, lane);
+    if (lane < 6) {
+        po[lane] = fp_canon(L.slot[X1][lane]);
+        po[6 + lane] = fp_canon(L.slot[Y1][lane]);
+    }
+    if (lane == 0) po[12] = 0;
+}
+
 // probe: a chain of dependent cooperative point operations on ONE wave (op 0: doubling, 1: mixed addition,
 // 2: general addition); the latency the low-latency kernel and the MSM tail are made of
 __global__ void __launch_bounds__(64) ssa_k_coop_bench(int op, int iters, u64 *out) {

@@ -97,6 +97,31 @@ def test_point_add_exceptional_cases(engine, oracle):
                 assert tuple(int(v) for v in got[i, 6:12]) == want[1], (general, i)
 
 
+def test_cooperative_point_operations(engine, oracle):
+    """the wave-cooperative doubling / mixed addition / general addition (low-latency kernel, MSM tail):
+    generic operands and every exceptional branch, operands given as scaled Jacobian points"""
+    import pymodel as m
+    g = m.default_params().generator()
+    p2, p3, p7 = m.pt_mul(2, g), m.pt_mul(3, g), m.pt_mul(7, g)
+    f = m.FIXTURE_SMALL_ORDER_PK
+    o2 = m.SMALL_ORDER_POINTS[2]
+    cases = [(g, p2), (g, g), (g, m.pt_neg(g)), (None, g), (g, None), (p3, p2), (p7, p3), (f, f), (f, m.pt_neg(f)),
+             (f, g), (None, None), (o2, o2), (o2, g), (p7, p7)]
+    for mode in (0, 1, 2):
+        a = _aff_rows([c[0] for c in cases])
+        b = _aff_rows([c[1] for c in cases])
+        a[:, 13] = mode
+        got = engine.debug_arith(7, a, b, 13)
+        for i, (x, y) in enumerate(cases):
+            want = m.pt_add(x, x) if mode == 2 else m.pt_add(x, y)
+            if want is None:
+                assert got[i, 12] == 1, (mode, i)
+            else:
+                assert got[i, 12] == 0, (mode, i)
+                assert tuple(int(v) for v in got[i, :6]) == want[0], (mode, i)
+                assert tuple(int(v) for v in got[i, 6:12]) == want[1], (mode, i)
+
+
 def test_scalar_mul_table_path(engine, oracle):
     import pymodel as m
     rng = np.random.default_rng(3)
