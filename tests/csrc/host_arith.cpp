@@ -44,7 +44,8 @@ int ha_decompress(const uint8_t *c49, uint64_t *o12, int *inf) {
     *inf = is_inf;
     return (int)s;
 }
-// [k]P through build_ptab + mul_ptab; tab must hold 8*24 u64
+// [k]P through build_ptab + mul_ptab; tab must hold ha_ptab_words() u64
+int ha_ptab_words(void) { return PTAB_ENTRIES * PTAB_ENTRY_U64; }
 int ha_mul_ptab(const uint64_t *k4, const uint64_t *p12, int inf, uint64_t *tab, uint64_t *o12) {
     sc256 k;
     for (int i = 0; i < 4; i++) k.w[i] = k4[i];
@@ -72,7 +73,7 @@ int ha_point_add(const uint64_t *a12, int a_inf, const uint64_t *b12, int b_inf,
     st(o12 + 6, a.y);
     return jac_is_identity(r);
 }
-// hash_field with the LDS planes emulated by a host array
+// hash_field with the LDS plane emulated by a host array (one plane: the MDS layer works in place)
 // flags != 0 forces the small-MDS path (the library derives the flag itself at ctx_create)
 void ha_hash_field(const void *params, int flags, const uint64_t *felts, uint32_t n, uint64_t *digest) {
     static uint64_t planes[RS_LDS_U64];
@@ -80,7 +81,7 @@ void ha_hash_field(const void *params, int flags, const uint64_t *felts, uint32_
     DevParams prm;
     memcpy(&prm, params, sizeof prm);
     prm.flags = (u32)flags;
-    sponge_hash(planes, planes + 12 * RS_STRIDE, &prm, n,
+    sponge_hash(planes, planes, &prm, n,
                 [&](u32 idx) -> u64 { return felts[idx]; }, d);
     for (int i = 0; i < 4; i++) digest[i] = d[i];
 }
@@ -90,7 +91,7 @@ void ha_hash_message(const void *params, const uint8_t *sig, const uint8_t *pk, 
     bool ok = true;
     fp6 rx = ld_fp6(sig, ok), px = ld_fp6(pk, ok);
     uint64_t d[4];
-    hash_message_lane(planes, planes + 12 * RS_STRIDE, (const DevParams *)params, rx, px,
+    hash_message_lane(planes, planes, (const DevParams *)params, rx, px,
                       ld_u64_le(pk + 48), msg, len, d);
     for (int i = 0; i < 4; i++) digest[i] = d[i];
 }

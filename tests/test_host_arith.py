@@ -112,7 +112,7 @@ def test_scalar_mul_table_path(ha, oracle):
     f = m.FIXTURE_SMALL_ORDER_PK
     ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, Q - 1, Q, Q + 1, 2**255 - 1, int("7" + "8" * 63, 16),
           int("7" * 64, 16), int("f" * 63, 16)] + [rnd.randrange(2**255) for _ in range(12)]
-    tab = np.zeros(8 * 24, np.uint64)
+    tab = np.zeros(ha.ha_ptab_words(), np.uint64)
     small = [m.SMALL_ORDER_POINTS[o] for o in (2, 5, 10)]
     for o, p in m.SMALL_ORDER_POINTS.items():
         assert m.on_curve(p) and m.pt_mul(o, p) is None
