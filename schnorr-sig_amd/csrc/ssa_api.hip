@@ -563,7 +563,7 @@ extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const ui
 extern "C" int ssa_bench_fpmul(ssa_ctx *ctx, int variant, double *fpmul_per_s) {
     if (!ctx || !fpmul_per_s) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (variant >= 10 && variant <= 12) {   // cooperative point-operation chain: result = operations per second
+    if (variant >= 10 && variant <= 13) {   // cooperative point-operation chain: result = operations per second
         if (ctx->st_aux.reserve(64)) return SSA_ERR_HIP;
         hipEvent_t c0, c1;
         HIP_TRY(hipEventCreate(&c0));

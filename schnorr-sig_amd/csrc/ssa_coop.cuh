@@ -190,58 +190,71 @@ COOP_FN int coop_pick(u32 g, int s0, int s1, int s2 = 0, int s3 = 0) {
     return g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : s3));
 }
 
-// (X, Y, Z) <- 2 (X, Y, Z), a = 1.  dbl-2007-bl with its squarings of sums turned back into products
-// (2 X YY = (X + YY)^2 - XX - YYYY, 2 Y Z = (Y + Z)^2 - YY - ZZ: with six lanes per product a product costs
-// what a square costs), so that every addition of the formula follows a product of its own lane group and the
-// doubling is FOUR rounds = four LDS round trips; t[0..5] scratch.
-//   R1  XX = X^2 -> M3 = 3 XX | YY = Y^2 | ZZ = Z^2 | Y Z -> Z3 = 2 Y Z
-//   R2  YY^2 -> E = 8 YYYY | X YY -> S = 4 X YY | ZZ^2 -> M = M3 + ZZ^2
-//   R3  M^2 -> X3 = M^2 - 2 S, W = S - X3
-//   R4  M W -> Y3 = M W - E
+// A cooperative point is FOUR consecutive slots P .. P+3 = (X, Y, Z, W) in modified Jacobian coordinates,
+// W = Z^4 (the curve's a is 1, so the doubling needs a Z^4 = W): carrying W takes one level off the doubling's
+// dependency chain -- three rounds instead of four -- and costs the additions nothing, their last two rounds
+// have idle lane groups for Z3^2 and Z3^4.  The identity is Z = 0 (W = 0).
+//
+// doubling, three rounds (t[0..3] scratch):
+//   R1  X^2 -> M = 3 X^2 + W | YY = Y^2 | Y Z -> Z3 = 2 Y Z
+//   R2  YY^2 -> E = 8 Y^4 | X YY -> S = 4 X YY | M^2 -> X3 = M^2 - 2 S, D = S - X3
+//       (+ with `fuse_qy >= 0`: Z3^2 and QY Z3, the first round of the mixed addition that follows)
+//   R3  D M -> Y3 = D M - E | E W -> W3 = 2 E W
 // Within a round the product part (uniform code) reads, the per-group tails write: no tail reads a slot that
-// another group's tail writes.
-COOP_FN void coop_jac_dbl(CoopLds &L, int X, int Y, int Z, const int *t, u32 lane, int ws = 0) {
-    const int YY = t[0], ZZ = t[1], M = t[2], E = t[3], S = t[4], W = t[5];
+// another group's tail writes.  coop_put stores value and 7x value; a plain store is used where the value is
+// only ever a first operand or a tail operand.
+COOP_FN void coop_jac_dbl(CoopLds &L, int P, const int *t, u32 lane, int ws = 0, int fuse_qy = -1,
+                          int fuse_z1z1 = 0, int fuse_qyz = 0) {
+    const int X = P, Y = P + 1, Z = P + 2, W = P + 3;
+    const int M = t[0], YY = t[1], E = t[2], D = t[3];
     COOP_LANE_ROLES(lane);
     (void)q;
     u64 r = 0;
-    if (g < 4) r = coop_group_mul(L.slot[coop_pick(g, X, Y, Z, Y)], L.slot[coop_pick(g, X, Y, Z, Z)], k, q);
-    if (g == 0) L.slot[M][k] = fp_add(fp_dbl(r), r);          // M3: a tail operand only, no 7x half
+    u64 pre = L.slot[W][k];     // tail operands are fetched before the products: their LDS latency hides
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, X, Y, Y)], L.slot[coop_pick(g, X, Y, Z)], k, q);
+    if (g == 0) coop_put(L, M, k, fp_add(fp_add(fp_dbl(r), r), pre));
     else if (g == 1) coop_put(L, YY, k, r);
-    else if (g == 2) coop_put(L, ZZ, k, r);
-    else if (g == 3) coop_put(L, Z, k, fp_dbl(r));
+    else if (g == 2) coop_put(L, Z, k, fp_dbl(r));
     coop_sync();
-    u64 pre = L.slot[M][k];     // tail operands are fetched before the products: their LDS latency hides
-    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, YY, X, ZZ)], L.slot[coop_pick(g, YY, YY, ZZ)], k, q);
-    if (g == 0) L.slot[E][k] = fp_dbl(fp_dbl(fp_dbl(r)));        // E, S: read by tails only, no 7x half
-    else if (g == 1) L.slot[S][k] = fp_dbl(fp_dbl(r));
-    else if (g == 2) coop_put(L, M, k, fp_add(r, pre));
-    coop_sync();
-    if (g == 0) {
-        pre = L.slot[S][k];
-        r = coop_group_mul(L.slot[M], L.slot[M], k, q);
-        const u64 x3 = fp_sub(r, fp_dbl(pre));
-        coop_put(L, X, k, x3);
-        L.slot[W][k] = fp_sub(pre, x3);     // W is the FIRST operand of R4: no 7x half needed
+    if (g < 3) {
+        r = coop_group_mul(L.slot[coop_pick(g, YY, X, M)], L.slot[coop_pick(g, YY, YY, M)], k, q);
+    } else if (fuse_qy >= 0 && g < 5) {
+        r = coop_group_mul(L.slot[g == 3 ? Z : fuse_qy], L.slot[Z], k, q);
+    }
+    {
+        const u64 s4 = fp_dbl(fp_dbl(__shfl(r, coop_lane_of(1, k))));     // S = 4 X YY, seen by every group
+        if (g == 0) {
+            L.slot[E][k] = fp_dbl(fp_dbl(fp_dbl(r)));
+        } else if (g == 2) {
+            const u64 x3 = fp_sub(r, fp_dbl(s4));
+            coop_put(L, X, k, x3);
+            L.slot[D][k] = fp_sub(s4, x3);
+        } else if (fuse_qy >= 0 && g == 3) {
+            coop_put(L, fuse_z1z1, k, r);
+        } else if (fuse_qy >= 0 && g == 4) {
+            L.slot[fuse_qyz][k] = r;
+        }
     }
     coop_sync();
-    if (g == 0) {
-        pre = L.slot[E][k];
-        r = coop_group_mul(L.slot[W], L.slot[M], k, q);
-        coop_put(L, Y, k, fp_sub(r, pre));
-    }
+    if (g == 0) pre = L.slot[E][k];
+    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, D, E)], L.slot[coop_pick(g, M, W)], k, q);
+    if (g == 0) coop_put(L, Y, k, fp_sub(r, pre));
+    else if (g == 1) coop_put(L, W, k, fp_dbl(r));
     coop_sync();
 }
 
-// (X, Y, Z) <- (X, Y, Z) + (QX, QY) affine, (0, 0) = identity; same case analysis as jac_madd.  Five rounds;
-// where an addition needs the product of a neighbouring group the value crosses by a wave shuffle.
+// P <- P + (QX, QY) affine, (0, 0) = identity; same case analysis as jac_madd.  Five rounds (four when the
+// doubling before it computed the first); where an addition needs the product of a neighbouring group the
+// value crosses by a wave shuffle.  t[0..8] scratch; with `prefused` t[4] = Z^2 and t[5] = QY Z are given.
 //   R1  Z1Z1 = Z^2 | QY Z
 //   R2  QX Z1Z1 -> H = U2 - X | (QY Z) Z1Z1 -> R = S2 - Y           (H = 0: doubling or the identity)
-//   R3  HH = H^2 | Z3 = Z H | W = R^2
-//   R4  HHH = H HH | V = X HH -> X3 = W - HHH - 2 V, D = V - X3
-//   R5  R D | Y HHH -> Y3 = R D - Y HHH
-COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, const int *t, u32 lane, int ws = 0) {
-    const int Z1Z1 = t[0], QYZ = t[1], H = t[2], R = t[3], HH = t[4], W = t[5], HHH = t[6], D = t[7];
+//   R3  HH = H^2 | Z3 = Z H | RR = R^2
+//   R4  HHH = HH H | V = HH X -> X3 = RR - HHH - 2 V, D = V - X3 | ZZ = Z3^2
+//   R5  D R | HHH Y -> Y3 = D R - HHH Y | W3 = ZZ^2
+COOP_FN void coop_jac_madd(CoopLds &L, int P, int QX, int QY, const int *t, u32 lane, int ws = 0,
+                           bool prefused = false) {
+    const int X = P, Y = P + 1, Z = P + 2, W = P + 3;
+    const int HH = t[0], RR = t[1], HHH = t[2], D = t[3], Z1Z1 = t[4], QYZ = t[5], H = t[6], R = t[7], ZZ = t[8];
     COOP_LANE_ROLES(lane);
     (void)q;
     const bool p_inf = coop_is_zero(L, Z, lane, ws);
@@ -251,14 +264,17 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
         if (g == 0) coop_put(L, X, k, L.slot[QX][k]);
         else if (g == 1) coop_put(L, Y, k, L.slot[QY][k]);
         else if (g == 2) coop_put(L, Z, k, k == 0 ? 1ull : 0ull);
+        else if (g == 3) coop_put(L, W, k, k == 0 ? 1ull : 0ull);
         coop_sync();
         return;
     }
     u64 r = 0;
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, Z, QY)], L.slot[Z], k, q);
-    if (g == 0) coop_put(L, Z1Z1, k, r);
-    else if (g == 1) L.slot[QYZ][k] = r;                    // only ever a first operand: no 7x half
-    coop_sync();
+    if (!prefused) {
+        if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, Z, QY)], L.slot[Z], k, q);
+        if (g == 0) coop_put(L, Z1Z1, k, r);
+        else if (g == 1) L.slot[QYZ][k] = r;
+        coop_sync();
+    }
     u64 pre = L.slot[coop_pick(g, X, Y)][k];
     if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, QX, QYZ)], L.slot[Z1Z1], k, q);
     if (g == 0) coop_put(L, H, k, fp_sub(r, pre));
@@ -266,19 +282,21 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
     coop_sync();
     if (coop_is_zero(L, H, lane, ws)) {
         if (coop_is_zero(L, R, lane, ws)) {
-            coop_jac_dbl(L, X, Y, Z, t, lane, ws);      // p == q
-        } else {
-            coop_set(L, Z, 0ull, lane, ws);             // p == -q
+            coop_jac_dbl(L, P, t, lane, ws);            // p == q
+        } else {                                        // p == -q
+            if (g == 0) coop_put(L, Z, k, 0ull);
+            else if (g == 1) coop_put(L, W, k, 0ull);
+            coop_sync();
         }
         return;
     }
     if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, Z, R)], L.slot[coop_pick(g, H, H, R)], k, q);
-    if (g == 0) L.slot[HH][k] = r;                          // HH, W: first operands / tail operands only
+    if (g == 0) L.slot[HH][k] = r;
     else if (g == 1) coop_put(L, Z, k, r);
-    else if (g == 2) L.slot[W][k] = r;
+    else if (g == 2) L.slot[RR][k] = r;
     coop_sync();
-    pre = L.slot[W][k];
-    if (g < 2) r = coop_group_mul(L.slot[HH], L.slot[coop_pick(g, H, X)], k, q);
+    pre = L.slot[RR][k];
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, HH, HH, Z)], L.slot[coop_pick(g, H, X, Z)], k, q);
     {
         const u64 hhh = __shfl(r, coop_lane_of(0, k));  // group 0's product, seen by every group
         if (g == 0) {
@@ -287,36 +305,42 @@ COOP_FN void coop_jac_madd(CoopLds &L, int X, int Y, int Z, int QX, int QY, cons
             const u64 x3 = fp_sub(fp_sub(pre, hhh), fp_dbl(r));
             coop_put(L, X, k, x3);
             L.slot[D][k] = fp_sub(r, x3);
+        } else if (g == 2) {
+            coop_put(L, ZZ, k, r);
         }
     }
     coop_sync();
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, D, HHH)], L.slot[coop_pick(g, R, Y)], k, q);
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, D, HHH, ZZ)], L.slot[coop_pick(g, R, Y, ZZ)], k, q);
     {
         const u64 yh = __shfl(r, coop_lane_of(1, k));   // group 1's product
         if (g == 0) coop_put(L, Y, k, fp_sub(r, yh));
+        else if (g == 2) coop_put(L, W, k, r);
     }
     coop_sync();
 }
 
-// (X1, Y1, Z1) <- (X1, Y1, Z1) + (X2, Y2, Z2), both Jacobian (add-1998-cmo-2), Z = 0 is the identity.
-// Five rounds; t[0..8] scratch.
+// P1 <- P1 + P2, both Jacobian (add-1998-cmo-2; P2 = slots X2, Y2, Z2, its W is not needed), Z = 0 is the
+// identity.  Five rounds; t[0..8] scratch.
 //   R1  A = Z1^2 | B = Z2^2 | C = Y1 Z2 | D = Y2 Z1 | E = Z1 Z2
 //   R2  U1 = X1 B | X2 A -> H = U2 - U1 | S1 = C B | D A -> R = S2 - S1      (H = 0: doubling or the identity)
-//   R3  HH = H^2 | Z3 = E H | W = R^2
-//   R4  HHH = H HH | V = U1 HH -> X3 = W - HHH - 2 V, F = V - X3
-//   R5  R F | S1 HHH -> Y3 = R F - S1 HHH
-COOP_FN void coop_jac_add(CoopLds &L, int X1, int Y1, int Z1, int X2, int Y2, int Z2, const int *t, u32 lane,
-                          int ws = 0) {
+//   R3  HH = H^2 | Z3 = E H | RR = R^2
+//   R4  HHH = H HH | V = U1 HH -> X3 = RR - HHH - 2 V, F = V - X3 | ZZ = Z3^2
+//   R5  R F | S1 HHH -> Y3 = R F - S1 HHH | W3 = ZZ^2
+COOP_FN void coop_jac_add(CoopLds &L, int P1, int P2, const int *t, u32 lane, int ws = 0) {
+    const int X1 = P1, Y1 = P1 + 1, Z1 = P1 + 2, W1 = P1 + 3, X2 = P2, Y2 = P2 + 1, Z2 = P2 + 2;
     const int A = t[0], B = t[1], C = t[2], Dd = t[3], E = t[4], U1 = t[5], S1 = t[6], H = t[7], R = t[8];
-    const int HH = t[0], W = t[1], HHH = t[2], F = t[3];
+    const int HH = t[0], RR = t[1], HHH = t[2], F = t[3], ZZ = t[4];
     COOP_LANE_ROLES(lane);
     (void)q;
     if (coop_is_zero(L, Z2, lane, ws)) return;
     if (coop_is_zero(L, Z1, lane, ws)) {
+        // copy X, Y, Z and rebuild W = Z^4
         if (g == 0) coop_put(L, X1, k, L.slot[X2][k]);
         else if (g == 1) coop_put(L, Y1, k, L.slot[Y2][k]);
         else if (g == 2) coop_put(L, Z1, k, L.slot[Z2][k]);
         coop_sync();
+        coop_mul(L, W1, Z1, Z1, lane, ws);
+        coop_mul(L, W1, W1, W1, lane, ws);
         return;
     }
     u64 r = 0;
@@ -338,33 +362,38 @@ COOP_FN void coop_jac_add(CoopLds &L, int X1, int Y1, int Z1, int X2, int Y2, in
     coop_sync();
     if (coop_is_zero(L, H, lane, ws)) {
         if (coop_is_zero(L, R, lane, ws)) {
-            coop_jac_dbl(L, X1, Y1, Z1, t, lane, ws);   // same point
-        } else {
-            coop_set(L, Z1, 0ull, lane, ws);            // opposite points
+            coop_jac_dbl(L, P1, t, lane, ws);           // same point
+        } else {                                        // opposite points
+            if (g == 0) coop_put(L, Z1, k, 0ull);
+            else if (g == 1) coop_put(L, W1, k, 0ull);
+            coop_sync();
         }
         return;
     }
     if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, E, R)], L.slot[coop_pick(g, H, H, R)], k, q);
     if (g == 0) coop_put(L, HH, k, r);
     else if (g == 1) coop_put(L, Z1, k, r);
-    else if (g == 2) coop_put(L, W, k, r);
+    else if (g == 2) coop_put(L, RR, k, r);
     coop_sync();
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, H, U1)], L.slot[HH], k, q);
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, H, U1, Z1)], L.slot[coop_pick(g, HH, HH, Z1)], k, q);
     {
         const u64 hhh = __shfl(r, coop_lane_of(0, k));
         if (g == 0) {
             coop_put(L, HHH, k, r);
         } else if (g == 1) {
-            const u64 x3 = fp_sub(fp_sub(L.slot[W][k], hhh), fp_dbl(r));
+            const u64 x3 = fp_sub(fp_sub(L.slot[RR][k], hhh), fp_dbl(r));
             coop_put(L, X1, k, x3);
             coop_put(L, F, k, fp_sub(r, x3));
+        } else if (g == 2) {
+            coop_put(L, ZZ, k, r);
         }
     }
     coop_sync();
-    if (g < 2) r = coop_group_mul(L.slot[coop_pick(g, R, S1)], L.slot[coop_pick(g, F, HHH)], k, q);
+    if (g < 3) r = coop_group_mul(L.slot[coop_pick(g, R, S1, ZZ)], L.slot[coop_pick(g, F, HHH, ZZ)], k, q);
     {
         const u64 sh = __shfl(r, coop_lane_of(1, k));
         if (g == 0) coop_put(L, Y1, k, fp_sub(r, sh));
+        else if (g == 2) coop_put(L, W1, k, r);
     }
     coop_sync();
 }
@@ -373,15 +402,16 @@ COOP_FN void coop_jac_add(CoopLds &L, int X1, int Y1, int Z1, int X2, int Y2, in
 // Signature::verify for ONE signature by ONE wave (reference src/signature.rs:181-205): the same
 // algorithm as ssa_k_hash + ssa_k_verify (affine table 1P..8P, signed 4-bit windows, comb for G,
 // x-only compare, optional [q]P == O first), every Fp6 operation spread over the wave.
-// LDS slot map: two per-wave working sets (accumulator, addend, nine temporaries, three for inversions)
-// and the slots both waves share (public key, signature x, the 8-entry table with rows X, Y, Z, C).
+// LDS slot map: two per-wave working sets (accumulator X, Y, Z, W, addend, nine temporaries, three for
+// inversions) and the slots both waves share (public key, signature x, the 8-entry table with rows X, Y, Z, C;
+// C holds W = Z^4 while the table is being built and the prefix products of the normalisation afterwards).
 namespace coop_slots {
-enum : int { WS_SLOTS = 17, PX = 2 * WS_SLOTS, PY, SX, TAB };
+enum : int { WS_SLOTS = 18, PX = 2 * WS_SLOTS, PY, SX, TAB };
 }
-#define COOP_WORKING_SET(ws)                                                                             \
-    const int AX = (ws) * coop_slots::WS_SLOTS, AY = AX + 1, AZ = AX + 2, QX = AX + 3, QY = AX + 4, T0 = AX + 5, \
-              I0 = AX + 14, I1 = AX + 15, I2 = AX + 16;                                                  \
-    (void)AY; (void)AZ; (void)QX; (void)QY; (void)T0; (void)I0; (void)I1; (void)I2
+#define COOP_WORKING_SET(ws)                                                                               \
+    const int AX = (ws) * coop_slots::WS_SLOTS, AY = AX + 1, AZ = AX + 2, AW = AX + 3, QX = AX + 4, QY = AX + 5,  \
+              T0 = AX + 6, I0 = AX + 15, I1 = AX + 16, I2 = AX + 17;                                           \
+    (void)AY; (void)AZ; (void)AW; (void)QX; (void)QY; (void)T0; (void)I0; (void)I1; (void)I2
 
 // Rescue-Prime permutation on the 12 lanes 0..11; state in plane L.st[0], L.st[1] is scratch
 COOP_FN void coop_rescue_permutation(CoopLds &L, const DevParams *__restrict__ prm, u32 lane, int ws = 0) {
@@ -469,20 +499,19 @@ COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane, int ws = 0) {
     coop_copy(L, row(0, 0), PX, lane, ws);
     coop_copy(L, row(0, 1), PY, lane, ws);
     coop_set(L, row(0, 2), 1ull, lane, ws);
+    coop_set(L, row(0, 3), 1ull, lane, ws);
     // (source row, operation): 2P = dbl 1P, 3P = 2P + P, 4P = dbl 2P, 5P = 4P + P, 6P = dbl 3P, 7P = 6P + P, 8P = dbl 4P
     const int src[7] = {0, 1, 1, 3, 2, 5, 3};
     const bool is_add[7] = {false, true, false, true, false, true, false};
 #pragma unroll 1
     for (int e = 1; e < 8; e++) {
         const int s = src[e - 1];
-        coop_copy(L, AX, row(s, 0), lane, ws);
-        coop_copy(L, AY, row(s, 1), lane, ws);
-        coop_copy(L, AZ, row(s, 2), lane, ws);
-        if (is_add[e - 1]) coop_jac_madd(L, AX, AY, AZ, PX, PY, t, lane, ws);
-        else coop_jac_dbl(L, AX, AY, AZ, t, lane, ws);
-        coop_copy(L, row(e, 0), AX, lane, ws);
-        coop_copy(L, row(e, 1), AY, lane, ws);
-        coop_copy(L, row(e, 2), AZ, lane, ws);
+#pragma unroll 1
+        for (int f = 0; f < 4; f++) coop_copy(L, AX + f, row(s, f), lane, ws);
+        if (is_add[e - 1]) coop_jac_madd(L, AX, PX, PY, t, lane, ws);
+        else coop_jac_dbl(L, AX, t, lane, ws);
+#pragma unroll 1
+        for (int f = 0; f < 4; f++) coop_copy(L, row(e, f), AX + f, lane, ws);
     }
     // Montgomery's trick over the (non-zero) Z's
     coop_set(L, QX, 1ull, lane, ws);                             // running prefix product
@@ -524,6 +553,7 @@ COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane, int ws = 0) {
     coop_set(L, AX, 1ull, lane, ws);
     coop_set(L, AY, 1ull, lane, ws);
     coop_set(L, AZ, 0ull, lane, ws);
+    coop_set(L, AW, 0ull, lane, ws);
     const u32 top = sc_nibble(kr, 63u);
     if (top != 0) {
         const int e = (int)top - 1;
@@ -531,19 +561,28 @@ COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane, int ws = 0) {
             coop_copy(L, AX, TAB + 4 * e, lane, ws);
             coop_copy(L, AY, TAB + 4 * e + 1, lane, ws);
             coop_set(L, AZ, 1ull, lane, ws);
+            coop_set(L, AW, 1ull, lane, ws);
         }
     }
 #pragma unroll 1
     for (int w = 62; w >= 0; w--) {
-#pragma unroll 1
-        for (int d = 0; d < 4; d++) coop_jac_dbl(L, AX, AY, AZ, t, lane, ws);
         const int digit = (int)sc_nibble(kr, (u32)w) - 8;
-        if (digit != 0) {
+        if (digit != 0) {   // the addend of this window (second operands only: no 7x halves needed)
             const int e = (digit < 0 ? -digit : digit) - 1;
-            coop_copy(L, QX, TAB + 4 * e, lane, ws);
-            if (digit < 0) coop_neg(L, QY, TAB + 4 * e + 1, lane, ws);
-            else coop_copy(L, QY, TAB + 4 * e + 1, lane, ws);
-            coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane, ws);
+            if (lane < 6) {
+                L.slot[QX][lane] = L.slot[TAB + 4 * e][lane];
+                const u64 y = L.slot[TAB + 4 * e + 1][lane];
+                L.slot[QY][lane] = digit < 0 ? fp_neg(y) : y;
+            }
+            coop_sync();
+        }
+#pragma unroll 1
+        for (int d = 0; d < 3; d++) coop_jac_dbl(L, AX, t, lane, ws);
+        if (digit != 0) {   // the fourth doubling also computes the first round of the addition
+            coop_jac_dbl(L, AX, t, lane, ws, QY, t[4], t[5]);
+            coop_jac_madd(L, AX, QX, QY, t, lane, ws, true);
+        } else {
+            coop_jac_dbl(L, AX, t, lane, ws);
         }
     }
 }
@@ -637,7 +676,7 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
                         L.slot[half ? QY : QX][c] = c < 6 ? v : fp_mul_small(v, 7u);
                     }
                     coop_sync();
-                    coop_jac_madd(L, AX, AY, AZ, QX, QY, t, lane, ws);
+                    coop_jac_madd(L, AX, QX, QY, t, lane, ws);
                 }
             }
             bool eq;

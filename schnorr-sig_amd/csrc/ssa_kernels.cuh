@@ -769,16 +769,18 @@ ssa_k_debug_coop(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
     if (i >= n) return;
     const u64 *pa = a + i * as, *pb = b + i * bs;
     const int mode = (int)pa[13];
-    enum { X1 = 0, Y1, Z1, X2, Y2, Z2, LAM, T0, T1, T2, TS = 12 };
+    enum { X1 = 0, Y1, Z1, W1, X2, Y2, Z2, LAM, T0, T1, T2, TS = 12 };
     int t[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) t[k] = TS + k;
-    // Jacobian (lam^2 x, lam^3 y, lam) of an affine point, (1, 1, 0) for the identity
-    auto lift = [&](const u64 *p, int X, int Y, int Z, const u64 (&lam)[6]) {
+    // modified Jacobian (lam^2 x, lam^3 y, lam, lam^4) of an affine point, (1, 1, 0, 0) for the identity
+    auto lift = [&](const u64 *p, int X, const u64 (&lam)[6], bool with_w) {
+        const int Y = X + 1, Z = X + 2, W = X + 3;
         if (p[12]) {
             coop_set(L, X, 1ull, lane);
             coop_set(L, Y, 1ull, lane);
             coop_set(L, Z, 0ull, lane);
+            if (with_w) coop_set(L, W, 0ull, lane);
             return;
         }
         coop_store7(L, X, p[lane % 6u], lane);
@@ -788,14 +790,15 @@ ssa_k_debug_coop(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
         coop_copy(L, Z, LAM, lane);
         coop_mul(L, T0, LAM, LAM, lane);
         coop_mul(L, X, X, T0, lane);
+        if (with_w) coop_mul(L, W, T0, T0, lane);
         coop_mul(L, T0, T0, LAM, lane);
         coop_mul(L, Y, Y, T0, lane);
     };
     const u64 lam1[6] = {3, 1, 4, 1, 5, 9}, lam2[6] = {2, 7, 1, 8, 2, 8};
-    lift(pa, X1, Y1, Z1, lam1);
+    lift(pa, X1, lam1, true);
     if (mode == 1) {
-        lift(pb, X2, Y2, Z2, lam2);
-        coop_jac_add(L, X1, Y1, Z1, X2, Y2, Z2, t, lane);
+        lift(pb, X2, lam2, false);
+        coop_jac_add(L, X1, X2, t, lane);
     } else if (mode == 0) {
         if (pb[12]) {
             coop_set(L, X2, 0ull, lane);
@@ -805,13 +808,17 @@ ssa_k_debug_coop(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
             coop_store7(L, Y2, pb[6 + lane % 6u], lane);
             coop_sync();
         }
-        coop_jac_madd(L, X1, Y1, Z1, X2, Y2, t, lane);
+        coop_jac_madd(L, X1, X2, Y2, t, lane);
     } else {
-        coop_jac_dbl(L, X1, Y1, Z1, t, lane);
+        coop_jac_dbl(L, X1, t, lane);
     }
+    // W must still be Z^4 (the next operation would rely on it)
+    coop_mul(L, T0, Z1, Z1, lane);
+    coop_mul(L, T0, T0, T0, lane);
+    const bool w_ok = coop_eq(L, T0, W1, lane);
     u64 *po = out + i * os;
     if (coop_is_zero(L, Z1, lane)) {
-        if (lane == 0) po[12] = 1;
+        if (lane == 0) po[12] = w_ok ? 1 : 99;
         return;
     }
     coop_inv(L, T0, Z1, T1, T2, LAM, lane);
@@ -823,11 +830,11 @@ ssa_k_debug_coop(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
         po[lane] = fp_canon(L.slot[X1][lane]);
         po[6 + lane] = fp_canon(L.slot[Y1][lane]);
     }
-    if (lane == 0) po[12] = 0;
+    if (lane == 0) po[12] = w_ok ? 0 : 99;
 }
 
 // probe: a chain of dependent cooperative point operations on ONE wave (op 0: doubling, 1: mixed addition,
-// 2: general addition); the latency the low-latency kernel and the MSM tail are made of
+// 2: general addition, 3: one ladder window); the latency the low-latency kernel and the MSM tail are made of
 __global__ void __launch_bounds__(64) ssa_k_coop_bench(int op, int iters, u64 *out) {
     __shared__ CoopLds L;
     const u32 lane = threadIdx.x;
@@ -840,9 +847,14 @@ __global__ void __launch_bounds__(64) ssa_k_coop_bench(int op, int iters, u64 *o
     coop_sync();
 #pragma unroll 1
     for (int i = 0; i < iters; i++) {
-        if (op == 0) coop_jac_dbl(L, 0, 1, 2, t, lane);
-        else if (op == 1) coop_jac_madd(L, 0, 1, 2, 3, 4, t, lane);
-        else coop_jac_add(L, 0, 1, 2, 3, 4, 5, t, lane);
+        if (op == 0) coop_jac_dbl(L, 0, t, lane);
+        else if (op == 1) coop_jac_madd(L, 0, 4, 5, t, lane);
+        else if (op == 2) coop_jac_add(L, 0, 4, t, lane);
+        else {   // one window of the ladder: 4 doublings + 1 mixed addition, first addition round fused
+            for (int d = 0; d < 3; d++) coop_jac_dbl(L, 0, t, lane);
+            coop_jac_dbl(L, 0, t, lane, 0, 5, t[4], t[5]);
+            coop_jac_madd(L, 0, 4, 5, t, lane, 0, true);
+        }
     }
     if (lane < 6) out[lane] = L.slot[0][lane] ^ L.slot[1][lane] ^ L.slot[2][lane];
 }

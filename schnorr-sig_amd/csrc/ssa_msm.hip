@@ -263,10 +263,11 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
         if (threadIdx.x == 0) *verdict = ST_MALFORMED;
         return;
     }
-    // slots: wave 0 accumulator 0..2, addend 3..5, scratch 6..14; wave 1 accumulator 20..22, addend 23..24, scratch 25..33
+    // slots: wave 0 accumulator 0..3 (X, Y, Z, W), addend 4..6, scratch 7..15; wave 1 accumulator 20..23,
+    // addend 24..25, scratch 26..34
     int t[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) t[k] = (ws ? 25 : 6) + k;
+    for (int k = 0; k < 9; k++) t[k] = (ws ? 26 : 7) + k;
     if (ws == 0) {
         auto load = [&](int s0, u32 j) {   // X, Y, Z of window j with their 7x halves
             if (lane < 36) {
@@ -277,12 +278,14 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
             coop_sync();
         };
         load(0, sh.windows - 1);
+        coop_mul(L, 3, 2, 2, lane, ws);    // W = Z^4 of the accumulator
+        coop_mul(L, 3, 3, 3, lane, ws);
 #pragma unroll 1
         for (int j = (int)sh.windows - 2; j >= 0; j--) {
 #pragma unroll 1
-            for (u32 d = 0; d < sh.c; d++) coop_jac_dbl(L, 0, 1, 2, t, lane, ws);
-            load(3, (u32)j);
-            coop_jac_add(L, 0, 1, 2, 3, 4, 5, t, lane, ws);
+            for (u32 d = 0; d < sh.c; d++) coop_jac_dbl(L, 0, t, lane, ws);
+            load(4, (u32)j);
+            coop_jac_add(L, 0, 4, t, lane, ws);
         }
     } else {
         sc256 acc;
@@ -319,6 +322,7 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
         coop_set(L, 20, 1ull, lane, ws);
         coop_set(L, 21, 1ull, lane, ws);
         coop_set(L, 22, 0ull, lane, ws);
+        coop_set(L, 23, 0ull, lane, ws);
 #pragma unroll 1
         for (int w = 0; w < GW_COUNT; w++) {      // BASEPOINT_TABLE.multiply_vartime
             const u32 d = sc_win16(lin, (u32)w);
@@ -327,10 +331,10 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
                 if (lane < 24) {
                     const u32 half = lane / 12u, c = lane % 12u;
                     const u64 v = rowp[6u * half + c % 6u];
-                    L.slot[half ? 24 : 23][c] = c < 6 ? v : fp_mul_small(v, 7u);
+                    L.slot[half ? 25 : 24][c] = c < 6 ? v : fp_mul_small(v, 7u);
                 }
                 coop_sync();
-                coop_jac_madd(L, 20, 21, 22, 23, 24, t, lane, ws);
+                coop_jac_madd(L, 20, 24, 25, t, lane, ws);
             }
         }
     }
@@ -342,11 +346,11 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
         if (li || ri) {
             eq = (li && ri) || (li && coop_is_zero(L, 20, lane, ws)) || (ri && coop_is_zero(L, 0, lane, ws));
         } else {
-            coop_mul(L, 6, 22, 22, lane, ws);
-            coop_mul(L, 6, 0, 6, lane, ws);
-            coop_mul(L, 7, 2, 2, lane, ws);
-            coop_mul(L, 7, 20, 7, lane, ws);
-            eq = coop_eq(L, 6, 7, lane, ws);
+            coop_mul(L, 7, 22, 22, lane, ws);
+            coop_mul(L, 7, 0, 7, lane, ws);
+            coop_mul(L, 8, 2, 2, lane, ws);
+            coop_mul(L, 8, 20, 8, lane, ws);
+            eq = coop_eq(L, 7, 8, lane, ws);
         }
         if (lane == 0) *verdict = eq ? ST_OK : ST_INVALID_SIG;
     }
