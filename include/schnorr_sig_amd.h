@@ -68,6 +68,7 @@ extern "C" {
 #define SSA_ERR_NO_DEVICE (-4)
 
 /* flags */
+#define SSA_MAX_BATCH ((size_t)1 << 30)   /* signatures per call; larger n returns SSA_ERR_ARG */
 #define SSA_FLAG_FORCE_LANE 2u    /* always the throughput kernels (one signature per lane) */
 #define SSA_FLAG_FORCE_COOP 4u    /* always the low-latency kernel (one wave per signature) */
 #define SSA_FLAG_CHECK_TORSION 1u /* Signature::verify semantics (src/signature.rs:182-184);

@@ -263,7 +263,7 @@ extern "C" int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, c
 
 extern "C" int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t n,
                                           uint8_t *d_pks_out, uint8_t *d_pk_inf_out, uint8_t *d_status_out) {
-    if (!ctx || (n && (!d_compressed || !d_pks_out || !d_status_out))) return SSA_ERR_ARG;
+    if (!ctx || (n && (!d_compressed || !d_pks_out || !d_status_out)) || n > SSA_MAX_BATCH) return SSA_ERR_ARG;
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(ctx->device));
     return timed_launch(ctx, "ssa_k_decompress", [&] {

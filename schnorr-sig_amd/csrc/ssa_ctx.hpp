@@ -93,6 +93,7 @@ static inline int timed_launch(ssa_ctx *ctx, const char *name, F &&launch) {
 // ---- argument checks and host->device staging shared by the entry points ----
 static inline int check_msgs(const uint8_t *msgs, const uint64_t *off, size_t stride, size_t len, size_t n) {
     if (n == 0) return 0;
+    if (n > SSA_MAX_BATCH) return SSA_ERR_ARG;   // grid sizes and workspace offsets are computed for n <= 2^30
     if (!off && len > 0 && !msgs) return SSA_ERR_ARG;
     if (!off && stride < len) return SSA_ERR_ARG;
     if (len > 0xffffffffull) return SSA_ERR_ARG;
