@@ -111,7 +111,8 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->st_msgs, &ctx->st_off, &ctx->st_status, &ctx->st_aux, &ctx->st_aux2, &ctx->msm_points,
                       &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
                       &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
-                      &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs})
+                      &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
+                      &ctx->msm_ids, &ctx->msm_ids2})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);

@@ -60,7 +60,7 @@ struct ssa_ctx {
     DevBuf st_sigs, st_pks, st_inf, st_msgs, st_off, st_status, st_aux, st_aux2;
     // MSM-form batch verification (ssa_msm.hip)
     DevBuf msm_points, msm_scalars, msm_keys, msm_vals, msm_keys2, msm_vals2, msm_sort_tmp, msm_bounds,
-        msm_buckets, msm_chunks, msm_windows, msm_partials, msm_flags, st_coeffs;
+        msm_buckets, msm_chunks, msm_windows, msm_partials, msm_flags, st_coeffs, msm_cnt, msm_cnt2, msm_ids, msm_ids2;
     bool timing = false;
     // batches up to these sizes take the cooperative (waves-per-signature) kernel: measured crossovers without /
     // with the subgroup check (tools/mode_crossover.py); SSA_COOP_MAX_N overrides both
