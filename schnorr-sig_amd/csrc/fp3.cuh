@@ -65,28 +65,71 @@ SSA_DEV fp3 f3_inv(const fp3 &a) {
     return f3_mul_fp(m, fp_inv(n.c[0]));
 }
 
+// Frobenius t -> w t (w = 7^((p-1)/3), a primitive cube root of unity): two multiplications by constants
+SSA_DEV fp3 f3_frob1(const fp3 &a) {
+    return fp3{{a.c[0], fp_mul(a.c[1], 0xfffffffe00000001ULL), fp_mul(a.c[2], 0x00000000ffffffffULL)}};
+}
+SSA_DEV fp3 f3_frob2(const fp3 &a) {
+    return fp3{{a.c[0], fp_mul(a.c[1], 0x00000000ffffffffULL), fp_mul(a.c[2], 0xfffffffe00000001ULL)}};
+}
+template <int N>
+SSA_DEV fp3 f3_sqr_n_mul(fp3 x, const fp3 &tail) {
+#pragma unroll 1
+    for (int i = 0; i < N; i++) x = f3_sqr(x);
+    return f3_mul(x, tail);
+}
+
 // Tonelli-Shanks constants: p^3 - 1 = 2^32 * T3, zeta = t^T3 generates the 2-Sylow subgroup (in Fp)
 constexpr u64 TS_ZETA_INV = 0x76b6b635b6fc8719ULL;     // zeta^-1, zeta = 0x185629dcda58878c
 constexpr u64 TS_CT = 0x676669cb3be57916ULL;           // t^-((T3+1)/2) = TS_CT * t
-// (T3 - 1) / 2 = 0x7ffffffe_80000002fffffffc_80000002fffffffe  (159 bits)
-SSA_DEV u64 ts_exp_limb(int i) {
-    switch (i) {
-        case 0: return 0x80000002fffffffeULL;
-        case 1: return 0x80000002fffffffcULL;
-        default: return 0x000000007ffffffeULL;
-    }
+
+// a^((T3-1)/2) without a 159-bit square-and-multiply: T3 = (2^32 - 1) N with N = p^2 + p + 1, hence
+//   (T3 - 1) / 2 = (2^31 - 1) N + p (p + 1) / 2      and      a^N = norm(a) in Fp,
+//   a^((T3-1)/2) = norm(a)^(2^31 - 1) * frob(a^((p+1)/2)),   (p + 1) / 2 = (2^32 - 1) 2^31 + 1:
+// 62 squarings + 6 products in Fp3, one norm and a 31-bit power in Fp (was 158 squarings + ~100 products).
+SSA_DEV fp3 f3_pow_ts(const fp3 &a) {
+    // norm
+    const fp3 m = f3_mul(f3_frob1(a), f3_frob2(a));
+    fp_acc s;
+    acc_init(s, a.c[0], m.c[0]);
+    acc_mac(s, a.c[1], fp_mul_small(m.c[2], 7u));
+    acc_mac(s, a.c[2], fp_mul_small(m.c[1], 7u));
+    const u64 n = acc_reduce(s);
+    // n^(2^31 - 1) (the ladder of fp_inv)
+    u64 n2 = fp_mul(fp_sqr(n), n);
+    u64 n4 = n2;
+    for (int i = 0; i < 2; i++) n4 = fp_sqr(n4);
+    n4 = fp_mul(n4, n2);
+    u64 n8 = n4;
+    for (int i = 0; i < 4; i++) n8 = fp_sqr(n8);
+    n8 = fp_mul(n8, n4);
+    u64 n16 = n8;
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) n16 = fp_sqr(n16);
+    n16 = fp_mul(n16, n8);
+    u64 n12 = n8;
+    for (int i = 0; i < 4; i++) n12 = fp_sqr(n12);
+    n12 = fp_mul(n12, n4);
+    u64 n14 = fp_sqr(fp_sqr(n12));
+    n14 = fp_mul(n14, n2);
+    const u64 n15 = fp_mul(fp_sqr(n14), n);
+    u64 n31 = n16;
+#pragma unroll 1
+    for (int i = 0; i < 15; i++) n31 = fp_sqr(n31);
+    n31 = fp_mul(n31, n15);
+    // a^((p+1)/2)
+    const fp3 x2 = f3_sqr_n_mul<1>(a, a);
+    const fp3 x4 = f3_sqr_n_mul<2>(x2, x2);
+    const fp3 x8 = f3_sqr_n_mul<4>(x4, x4);
+    const fp3 x16 = f3_sqr_n_mul<8>(x8, x8);
+    const fp3 x32 = f3_sqr_n_mul<16>(x16, x16);      // a^(2^32 - 1)
+    const fp3 h = f3_sqr_n_mul<31>(x32, a);          // a^((2^32 - 1) 2^31 + 1)
+    return f3_mul_fp(f3_frob1(h), n31);
 }
 
 // y with y^2 == a (returns true) or y^2 == a / t (returns false: a is a non-square).  a != 0.
 SSA_DEV bool f3_sqrt_or_nonres(const fp3 &a, fp3 &y) {
-    // w = a^((T3-1)/2) by square-and-multiply (msb first; bit 158 is the top set bit)
-    fp3 w = a;
-#pragma unroll 1
-    for (int bit = 157; bit >= 0; bit--) {
-        w = f3_sqr(w);
-        const u64 limb = bit >= 128 ? ts_exp_limb(2) : (bit >= 64 ? ts_exp_limb(1) : ts_exp_limb(0));
-        if ((limb >> (bit & 63)) & 1ull) w = f3_mul(w, a);
-    }
+    const fp3 w = f3_pow_ts(a);          // a^((T3-1)/2)
     const fp3 x = f3_mul(a, w);          // a^((T3+1)/2)
     const fp3 b3 = f3_mul(x, w);         // a^T3, an element of Fp of 2-power order
     u64 c = b3.c[0];
