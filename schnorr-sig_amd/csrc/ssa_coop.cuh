@@ -1,14 +1,15 @@
 // Wave-cooperative arithmetic: ONE WAVE works on ONE point / ONE signature.
 //
-// The per-lane kernels (ssa_kernels.cuh) need ~65 k lanes to fill the chip and take ~8 ms per call
-// however small the batch is, because a lane runs its ~330 point operations serially.  Here a wave
-// shares the work of one point operation: Fp6 values live in LDS slots, independent products of a formula
-// run side by side (six lanes per product, one LDS round trip per round), a lone product is spread over 36
-// lanes, and the additions between the products are folded into a few linear steps.  Used for (1) the sequential tail of the MSM reduction (ssa_msm.hip) and (2) the
-// low-latency verification kernel ssa_k_verify_coop (small batches, single Signature::verify calls).
+// The per-lane kernels (ssa_kernels.cuh) need ~65 k lanes to fill the chip and take 5-8 ms per call however
+// small the batch is, because a lane runs its ~330 point operations serially.  Here a wave shares the work of
+// one point operation: Fp6 values live in LDS slots; the independent products of a formula run side by side
+// (twelve lanes per product, one LDS round trip per round) with the formula's additions folded into the tail
+// of the round that produces their operands; a lone product (inversions, comparisons) is spread over 36 lanes.
+// Used for (1) the sequential tail of the MSM reduction (ssa_msm.hip) and (2) the low-latency verification
+// kernel ssa_k_verify_coop (small batches, single Signature::verify calls).
 //
-// Every function here must be called by ALL 64 threads of a one-wave block (blockDim.x == 64);
-// Fp6 values are LDS slots addressed by index, booleans returned are wave-uniform.
+// Every function here must be called by ALL 64 lanes of the wave that owns the working set; Fp6 values are
+// LDS slots addressed by index, booleans returned are wave-uniform.
 #pragma once
 // (included at the end of ssa_kernels.cuh: uses its byte loaders, msg_felt and status codes)
 
@@ -18,8 +19,8 @@ constexpr int COOP_SLOTS = 72;
 
 // A slot holds an Fp6 value v (words 0..5) and 7*v (words 6..11): the product rounds read the wrapped
 // terms (u^6 = 7) of their second operand from the upper half, so nobody scales on the critical path.
-// Every primitive below keeps the upper half valid; code that stores into a slot by hand must do the same
-// (coop_store7).
+// The generic primitives keep the upper half valid (coop_store7 / coop_put); the hand-scheduled point
+// operations skip it for values that are only ever first operands or tail operands (noted where they do).
 struct CoopLds {
     u64 slot[COOP_SLOTS][12];
     u64 part[2][6][6][3];     // coop_mul: per cooperating wave, products grouped by output coefficient
