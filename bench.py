@@ -2,19 +2,33 @@
 """bench.py -- Schnorr verifications/sec on MI355X (BASELINE.json metric).
 
 A step = one pass of the hot path (hash_message -> [h]P + [e]G -> x-compare -> wave-ballot
-aggregate) over one batch of 2^20 synthetic signatures per GPU, inputs resident in HBM.
+aggregate) over one batch of synthetic signatures per GPU, inputs resident in HBM.
 Workload: SURVEY.md §8(d) config 3 (random keypairs, one signature each, distinct 80-byte
 messages), generated on the GPU by the engine's own keygen/sign kernel.  Semantics of the
 headline number: verify_batch (src/batch.rs: no torsion check); the Signature::verify number
 (with the [q]P subgroup check, src/signature.rs:182) is reported beside it.
 
-Multi-GPU (torchrun, one rank per GPU): the batch shards by signature, no data-path collective;
-the only exchange is one 8-byte all-reduce of the rejection counts per step (RCCL).
+Multi-GPU: one process per GPU over RCCL.  The batch shards by signature, no data-path
+collective; the only exchange is one 8-byte all-reduce of the rejection counts per step.
+  * under torchrun (WORLD_SIZE set, as the driver launches it) this process is one rank;
+  * `python bench.py --gpus N` with N > 1 and no WORLD_SIZE: this process only LAUNCHES -- it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child before any GPU call
+    and exits with the child's status (it never re-execs and never touches the GPU itself).
+Modes:
+  default          weak scaling: 2^20 signatures per GPU (the metric's batch size on every GPU)
+  --total T        strong scaling (config 4: T = 4194304): ONE batch of T signatures generated on
+                   rank 0, distributed by direct scatter (timed: scatter_ms) and -- for comparison,
+                   SURVEY.md §8(e) "report both" -- by broadcast of the whole arrays (broadcast_ms),
+                   each rank verifying its contiguous shard
+With N > 1 the weak run also carries a short config-4 leg (`config4_strong`) so that one driver
+invocation records both.
 """
 import argparse
+import hashlib
 import json
-import numpy as np
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,90 +47,296 @@ W_TABLE = 4 * W_DBL + 3 * W_MADD + 18 * F6_MUL + W_INV + 7 * (3 * F6_MUL + F6_SQ
 W_BASE = 16 * W_MADD                            # comb, 16-bit windows
 W_FINAL = F6_MUL + F6_SQR + 2 * F6_SQR + F6_MUL  # x*Z^2 compare + on-curve check
 W_VERIFY_KERNEL = W_TABLE + W_LADDER + W_BASE + W_FINAL
+W_VERIFY_KEYED = W_LADDER + W_BASE + F6_MUL + F6_SQR   # keyed context: table and key checks are cached
 W_TORSION = W_LADDER
 W_HASH = 4 * 7 * (12 * 4 + 12 * 72 + 2 * 144)   # 4 permutations x 7 rounds (80-byte message)
 BYTES_PER_VERIFY = 81 + 96 + 80 + 1             # algorithmic HBM bytes
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9            # MI355X_MICROARCH.md: 256 CU x 4 SIMD-32 x 2.4 GHz
 PEAK_FPMUL = VALU_LANE_OPS / 16                 # 4 quarter-rate v_mad_u64_u32 per product, nothing else
 PEAK_HBM_GBPS = 8000.0
+LIB = os.path.join(ROOT, "schnorr-sig_amd", "csrc", "libschnorr_sig_amd.so")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", dest="n", type=int, default=1 << 20, help="signatures per GPU per step")
+    ap.add_argument("--batch", dest="n", type=int, default=1 << 20, help="signatures per GPU per step (weak mode)")
+    ap.add_argument("--total", type=int, default=0,
+                    help="strong scaling: ONE batch of this many signatures sharded over the GPUs "
+                         "(config 4: 4194304); overrides --batch")
     ap.add_argument("--corrupt", type=float, default=0.0, help="fraction of corrupted signatures (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
-    ap.add_argument("--skip-torsion-leg", action="store_true", help="profiling runs: only the timed steps")
-    ap.add_argument("--distribute", action="store_true",
-                    help="N>1: generate the whole batch on rank 0 and scatter the shards over RCCL (timed "
-                         "separately as scatter_ms) instead of generating each shard in place")
-    args = ap.parse_args()
+    ap.add_argument("--skip-torsion-leg", action="store_true",
+                    help="profiling runs: only the timed steps (no torsion / MSM / host-path / keyed legs)")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N>1 weak run: skip the config-4 leg")
+    ap.add_argument("--strong-total", type=int, default=1 << 22, help="batch size of the config-4 leg")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="rank/launch/collective plumbing with NO GPU work (CPU test of the N>1 launch path; "
+                         "prints value 0 and \"plumbing_only\": true -- never a measurement)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): start N ranks as a CHILD torchrun and exit with
+    its status.  Nothing here initialises the GPU (device_count() does not on this image), and nothing is
+    exec'ed: the children are fresh processes."""
+    backend = os.environ.get("SSA_BENCH_BACKEND", "gloo" if args.plumbing_only else "nccl")
+    if backend == "nccl":
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d needs %d devices, this node has %d (%d ranks, %d device%s): "
+                             "refusing to run ranks that would share a GPU\n"
+                             % (args.gpus, args.gpus, ndev, args.gpus, ndev, "" if ndev == 1 else "s"))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SSA_BENCH_BACKEND"] = backend
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def lib_sha256():
+    h = hashlib.sha256()
+    with open(LIB, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def pmc_for_loaded_library(n):
+    """HBM traffic / VALU counters from the committed PMC passes -- only if they were measured on the very
+    library this process has loaded (profiles/*/hbm_traffic.json carries its sha256) and at this batch size."""
+    sha = lib_sha256()
+    best = None
+    prof = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        p = os.path.join(prof, d, "hbm_traffic.json")
+        if os.path.exists(p):
+            try:
+                j = json.load(open(p))
+            except Exception:
+                continue
+            if j.get("lib_sha256") == sha and int(j.get("batch", 0)) == n:
+                best = (p, j)
+    if best is None:
+        return None, "no profiles/*/hbm_traffic.json measured on the loaded library (sha256 %s...) at n=%d" % (sha[:12], n)
+    return best[1], os.path.relpath(best[0], ROOT)
+
+
+class Ranks:
+    """rank / device / process-group plumbing of one bench process"""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = os.environ.get("SSA_BENCH_BACKEND", "gloo" if args.plumbing_only else "nccl")
+        self.dist = None
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` or "
+                             "`torchrun --nproc-per-node N bench.py --gpus N`" % (args.gpus, self.world))
+        import torch
+        self.torch = torch
+        self.dev_index = None
+        if not args.plumbing_only:
+            ndev = torch.cuda.device_count()
+            if self.backend == "nccl":
+                if self.local_rank >= ndev:
+                    raise SystemExit("bench.py: rank %d has no device of its own (%d ranks, %d devices)"
+                                     % (self.rank, self.world, ndev))
+                self.dev_index = self.local_rank
+            else:       # rehearsal backend on a box with fewer GPUs than ranks: ranks share devices
+                self.dev_index = self.local_rank % max(ndev, 1)
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
+            else:
+                dist.init_process_group(self.backend)
+            assert dist.get_world_size() == args.gpus and dist.get_rank() == self.rank
+            self.dist = dist
+        if self.dev_index is not None:
+            torch.cuda.set_device(self.dev_index)
+            self.dev = torch.device("cuda", self.dev_index)
+        else:
+            self.dev = torch.device("cpu")
+
+    @property
+    def on_device_collectives(self):
+        return self.backend == "nccl"
+
+    def all_reduce_sum(self, t):
+        if self.dist is None:
+            return t
+        if self.on_device_collectives or t.device.type == "cpu":
+            self.dist.all_reduce(t)
+        else:                     # rehearsal backend: through the host
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+        return t
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.on_device_collectives else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sync_all(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.dev.type == "cuda":
+            self.torch.cuda.synchronize()
+
+    def device_report(self):
+        """[(rank, device index, device name, pci bus id)] gathered on every rank"""
+        torch = self.torch
+        if self.dev.type == "cuda":
+            p = torch.cuda.get_device_properties(self.dev)
+            mine = (self.rank, self.dev_index, p.name, getattr(p, "pci_bus_id", None), getattr(p, "uuid", None) and str(p.uuid))
+        else:
+            mine = (self.rank, None, "cpu (plumbing only)", None, None)
+        if self.dist is None:
+            return [mine]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, mine)
+        return out
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def plumbing_only(args, rk):
+    """N>1 launch path without GPU work (CPU test): same barrier / max-over-ranks / all-reduce sequence."""
+    torch = rk.torch
+    nfail = torch.zeros(1, dtype=torch.int64)
+    rk.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nfail.fill_(rk.rank + 1)
+        rk.all_reduce_sum(nfail)
+    rk.sync_all()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+    devices = rk.device_report()
+    if rk.rank == 0:
+        print(json.dumps({"metric": "plumbing only (no GPU work, not a measurement)", "value": 0.0,
+                          "unit": "verifications/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "plumbing_only": True, "backend": rk.backend,
+                          "all_reduce_sum": int(nfail.item()), "ranks": [list(d) for d in devices]}))
+    rk.finish()
+
+
+def gen_batch(torch, eng, dev, n, seed, chunk=1 << 20):
+    """config-3 inputs on the device: (sigs, pks, msgs) for n random keypairs, 80-byte distinct messages"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    pks = torch.empty((n, 96), dtype=torch.uint8, device=dev)
+    sigs = torch.empty((n, 81), dtype=torch.uint8, device=dev)
+    msgs = torch.randint(0, 256, (n, 80), dtype=torch.uint8, device=dev, generator=g)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        sks = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=g)
+        nonces = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev, generator=g)
+        sks[:, 31] &= 0x3F      # < 2^254 < q
+        nonces[:, 31] &= 0x3F
+        sks[:, 0] |= 1          # never zero
+        nonces[:, 0] |= 1
+        eng.keygen_sign_many_device(sks.data_ptr(), nonces.data_ptr(), msgs[lo:lo + m].data_ptr(), m, 80,
+                                    pks[lo:lo + m].data_ptr(), sigs[lo:lo + m].data_ptr())
+        eng.sync()
+    return sigs, pks, msgs, g
+
+
+def distribute(rk, full, total, how):
+    """rank-0-resident (sigs, pks, msgs) -> this rank's contiguous shard; returns (shard tensors, milliseconds).
+    how = "scatter": every shard crosses one link once; "broadcast": the whole arrays go to every rank."""
+    from schnorr_sig_amd.sharding import broadcast_rows, scatter_rows, shard_range
+    torch = rk.torch
+    lo, hi = shard_range(total, rk.rank, rk.world)
+    widths = (81, 96, 80)
+    rk.sync_all()
+    t0 = time.perf_counter()
+    out = []
+    for t_, w in zip(full, widths):
+        if rk.on_device_collectives:
+            fn = scatter_rows if how == "scatter" else broadcast_rows
+            out.append(fn(t_, total, w, rk.rank, rk.world, rk.dist, device=rk.dev))
+        else:       # rehearsal backend: through the host
+            fn = scatter_rows if how == "scatter" else broadcast_rows
+            got = fn(t_.cpu() if t_ is not None else None, total, w, rk.rank, rk.world, rk.dist, device="cpu")
+            out.append(got.to(rk.dev))
+    rk.sync_all()
+    ms = rk.max_over_ranks(time.perf_counter() - t0) * 1e3
+    assert all(o.shape[0] == hi - lo for o in out)
+    return out, ms
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    rk = Ranks(args)
+    if args.plumbing_only:
+        return plumbing_only(args, rk)
 
     import numpy as np
-    import torch
+    torch = rk.torch
     import schnorr_sig_amd as ssa
+    from schnorr_sig_amd.sharding import shard_range
+    rank, world, dev = rk.rank, rk.world, rk.dev
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    # SSA_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks share a
-    # device; RCCL refuses that).  The driver's runs use the default: nccl == RCCL, one GPU per rank.
-    backend = os.environ.get("SSA_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    n = args.n
-
-    eng = ssa.Engine(dev_index)
-    # one explicit stream for everything: the engine's kernels, torch's fills and the collectives.
-    # (torch's default stream has handle 0, which the C ABI reads as "use the context's own stream".)
+    eng = ssa.Engine(rk.dev_index)
+    # one explicit stream for everything: the engine's kernels, torch's fills and the collectives
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
 
-    # ---- synthetic inputs, generated on the device (seed per rank) ----
-    g = torch.Generator(device=dev)
-    g.manual_seed(0x5C4E0222 + rank)
-    sks = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
-    nonces = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
-    sks[:, 31] &= 0x3F      # < 2^254 < q
-    nonces[:, 31] &= 0x3F
-    sks[:, 0] |= 1          # never zero
-    nonces[:, 0] |= 1
-    msgs = torch.randint(0, 256, (n, 80), dtype=torch.uint8, device=dev, generator=g)
-    pks = torch.empty((n, 96), dtype=torch.uint8, device=dev)
-    sigs = torch.empty((n, 81), dtype=torch.uint8, device=dev)
-    eng.keygen_sign_many_device(sks.data_ptr(), nonces.data_ptr(), msgs.data_ptr(), n, 80, pks.data_ptr(),
-                                sigs.data_ptr())
-    eng.sync()
-    scatter_ms = None
-    if args.distribute and dist is not None:
-        # rank 0 holds the whole world*n batch (its own shard repeated is enough to exercise the path:
-        # what matters is bytes moved); every rank receives its shard by direct scatter
-        from schnorr_sig_amd.sharding import scatter_rows
-        torch.cuda.synchronize()
-        dist.barrier()
-        ts = time.perf_counter()
-        full = {}
-        for name, t_, w in (("sigs", sigs, 81), ("pks", pks, 96), ("msgs", msgs, 80)):
-            full[name] = t_.repeat(world, 1) if rank == 0 else None
-            got = scatter_rows(full[name], world * n, w, rank, world, dist, device=dev)
-            t_.copy_(got)
-        torch.cuda.synchronize()
-        dist.barrier()
-        scatter_ms = (time.perf_counter() - ts) * 1e3
+    strong = args.total > 0
+    scatter_ms = broadcast_ms = None
+    if strong:
+        total = args.total
+        full = (None, None, None)
+        if rank == 0:
+            s_, p_, m_, g = gen_batch(torch, eng, dev, total, 0x5C4E0224)
+            full = (s_, p_, m_)
+        if world > 1:
+            (sigs_b, pks_b, msgs_b), broadcast_ms = distribute(rk, full, total, "broadcast")
+            del sigs_b, pks_b, msgs_b
+            (sigs, pks, msgs), scatter_ms = distribute(rk, full, total, "scatter")
+            sigs, pks, msgs = sigs.contiguous(), pks.contiguous(), msgs.contiguous()
+        else:
+            sigs, pks, msgs = full
         del full
+        lo, hi = shard_range(total, rank, world)
+        n = hi - lo
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x5C4E0224 + 7 * rank + 1)
+        n_all = total
+    else:
+        n = args.n
+        sigs, pks, msgs, g = gen_batch(torch, eng, dev, n, 0x5C4E0222 + rank)
+        n_all = n * world
+
     n_bad_expected = 0
     if args.corrupt > 0:
         n_bad_expected = int(n * args.corrupt)
@@ -126,64 +346,50 @@ def main():
         msgs[idx[third:2 * third], 40] ^= 0x10           # message bit flip
         rest = idx[2 * third:]
         sigs[rest, :49] = sigs[(rest + 1) % n, :49]      # someone else's R (canonical, on curve)
-    status = torch.empty(n, dtype=torch.uint8, device=dev)
+    status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
     nfail = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step(check_torsion=False):
         eng.verify_many_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, status.data_ptr(),
                                nfail.data_ptr(), check_torsion=check_torsion)
-        if dist is not None:
-            if backend == "nccl":
-                dist.all_reduce(nfail)   # aggregate verdict of the sharded batch (RCCL, 8 bytes)
-            else:                        # rehearsal backend: reduce through the host
-                host = nfail.cpu()
-                dist.all_reduce(host)
-                nfail.copy_(host)
-
-    def sync_all():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        rk.all_reduce_sum(nfail)     # aggregate verdict of the sharded batch (RCCL, 8 bytes)
 
     for _ in range(args.warmup):
         step()
-    sync_all()
+    rk.sync_all()
     eng.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    sync_all()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    rk.sync_all()
+    elapsed = time.perf_counter() - t0
     eng.enable_timing(False)
     k_verify_ms, k_cnt = eng.read_timing("ssa_k_verify")
     k_hash_ms, _ = eng.read_timing("ssa_k_hash")
     total_fail = int(nfail.item())
-    if os.environ.get("SSA_BENCH_DEBUG"):
-        print("[rank %d] total_fail after all-reduce = %d, local status!=0 = %d" %
-              (rank, total_fail, int((status != 0).sum().item())), file=sys.stderr)
-    ok = (total_fail == n_bad_expected * world) if args.corrupt > 0 else (total_fail == 0)
+    status_batch_semantics = status[:min(n, args.cpu_sample)].clone()   # what the CPU leg is compared with
+    bad_total = torch.tensor([n_bad_expected], dtype=torch.int64, device=dev)
+    rk.all_reduce_sum(bad_total)
+    ok = total_fail == int(bad_total.item())
+    elapsed = rk.max_over_ranks(elapsed)
+    devices = rk.device_report()
+    legs = not args.skip_torsion_leg
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- Signature::verify semantics (torsion check on), 2 steps, rank 0 reports ----
+    # ---- Signature::verify semantics (torsion check on), 2 steps ----
     torsion_rate, total_fail_t = None, None
-    if not args.skip_torsion_leg:
+    if legs:
         step(check_torsion=True)
-        sync_all()
+        rk.sync_all()
         t2 = time.perf_counter()
         for _ in range(2):
             step(check_torsion=True)
-        sync_all()
-        torsion_rate = world * n * 2 / (time.perf_counter() - t2)
+        rk.sync_all()
+        torsion_rate = n_all * 2 / rk.max_over_ranks(time.perf_counter() - t2)
         total_fail_t = int(nfail.item())
 
     # ---- the reference's own MSM-form verify_batch (one verdict per batch), 3 steps ----
     msm = None
-    if not args.skip_torsion_leg:
+    if legs and n > 0:
         coeffs = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device=dev, generator=g)
         verdict = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -191,37 +397,52 @@ def main():
             eng.verify_batch_msm_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, coeffs.data_ptr(),
                                         16, verdict.data_ptr())
         msm_step()
-        sync_all()
+        rk.sync_all()
         eng.enable_timing(True)
         t3 = time.perf_counter()
         for _ in range(3):
             msm_step()
-        sync_all()
-        dt = time.perf_counter() - t3
+        rk.sync_all()
+        dt = rk.max_over_ranks(time.perf_counter() - t3)
         eng.enable_timing(False)
         stages = {k: eng.read_timing(k)[0] for k in ("ssa_k_hash", "msm_k_prepare", "msm_sort", "msm_k_buckets",
                                                      "msm_reduce")}
-        msm = {"verifications_per_sec": world * n * 3 / dt, "ms_per_batch": dt / 3 * 1e3,
-               "verdict": int(verdict.item()), "expected_verdict": 2 if args.corrupt > 0 else 0, "stages_ms": stages}
+        msm = {"verifications_per_sec": n_all * 3 / dt, "ms_per_batch": dt / 3 * 1e3,
+               "verdict": int(verdict.item()), "expected_verdict": 2 if args.corrupt > 0 else 0, "stages_ms": stages,
+               "note": "one verdict per rank-local shard (per-device partial sums are combined by "
+                       "ssa_multi_verify_batch_msm when one process owns the whole batch)"}
+
+    # ---- host-buffer entry point (what the Rust shim binds): PCIe-inclusive, never `value` ----
+    host_path = None
+    if legs and rank == 0 and n > 0 and hasattr(eng, "host_path_probe"):
+        host_path = eng.host_path_probe(sigs, pks, msgs, n, reps=3)
+
+    # ---- keyed context: repeated public keys (validator sets), Signature::verify semantics ----
+    keyed = None
+    if legs and rank == 0 and n > 0 and hasattr(eng, "keyset_create"):
+        keyed = keyed_leg(torch, eng, dev, g, min(n, 1 << 20))
+
+    # ---- config 4 beside the weak run: one 2^22 batch, rank 0 -> shards, verified once per step ----
+    config4 = None
+    if legs and world > 1 and not strong and not args.no_strong_leg:
+        config4 = strong_leg(rk, eng, args.strong_total)
 
     if rank == 0:
-        value = world * n * args.steps / elapsed
+        value = n_all * args.steps / elapsed
         w_kernel = W_VERIFY_KERNEL
         achieved = w_kernel * n / (k_verify_ms * 1e-3) if k_verify_ms > 0 else 0.0
-        traffic, valu_util = None, None   # from the committed PMC passes of the same workload (profiles/r01)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic_v5.json")) as fh:
-                if n == 1 << 20:
-                    pmc = json.load(fh)["ssa_k_verify"]
-                    traffic, valu_util = pmc["hbm_bytes_per_launch"], pmc["valu_issue_utilisation"]
-        except Exception:
-            pass
+        pmc, pmc_src = pmc_for_loaded_library(n)
+        traffic = pmc["ssa_k_verify"]["hbm_bytes_per_launch"] if pmc else None
         metric = "Schnorr verifications/sec, 2^20-sig batch, 1/2/4/8 MI355X; bit-exact vs CPU"
         try:
             with open(os.path.join(ROOT, "BASELINE.json")) as fh:
                 metric = json.load(fh)["metric"]
         except Exception:
             pass
+        unpinned = eng.uses_default_params() if hasattr(eng, "uses_default_params") else True
+        workload = ("config4: ONE batch of %d random-keypair signatures sharded over %d GPU(s)" % (n_all, world)
+                    if strong else "config3: 2^20 random-keypair signatures per GPU") + \
+            ", 80-byte distinct messages, full verify (Rescue hash + [h]P+[e]G + x-compare), verify_batch semantics"
         out = {
             "metric": metric,
             "value": value,
@@ -231,21 +452,29 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "config3: 2^20 random-keypair signatures per GPU, 80-byte distinct messages, "
-                                   "full verify (Rescue hash + [h]P+[e]G + x-compare), verify_batch semantics",
-                       "signatures_per_gpu": n, "message_bytes": 80, "parallelism": "shard%d" % world,
-                       "corrupt_fraction": args.corrupt},
+            "config": {"workload": workload, "signatures_per_gpu": n, "signatures_total": n_all, "message_bytes": 80,
+                       "parallelism": "shard%d" % world, "corrupt_fraction": args.corrupt,
+                       "backend": rk.backend if world > 1 else None},
+            "ranks": [list(d) for d in devices],
+            "constants": "builder-default (unpinned)" if unpinned else "caller-supplied blob",
+            "parity_unpinned": bool(unpinned),
+            "parity_note": "bit-exact against the CPU restatement (oracle/); Rescue constants and generator are not "
+                           "upstream's until tools/blob_from_upstream.py + tests/golden/upstream_vectors.json close it",
             "all_verdicts_as_expected": bool(ok),
             "rejected": total_fail,
             "with_torsion_check_verifications_per_sec": torsion_rate,
             "with_torsion_check_rejected": total_fail_t,
             "kernels_ms": {"ssa_k_verify": k_verify_ms, "ssa_k_hash": k_hash_ms, "launches": k_cnt},
             "verify_batch_msm_form": msm,
+            "host_path": host_path,
+            "keyed_context": keyed,
             "scatter_ms": scatter_ms,
+            "broadcast_ms": broadcast_ms,
+            "config4_strong": config4,
             "roofline": {
                 "bound": "valu",
                 "bound_note": "64-bit integer VALU (v_mad_u64_u32), neither hbm nor mfma: SURVEY.md 8(d); peak = "
@@ -257,8 +486,17 @@ def main():
                 "frac": achieved / PEAK_FPMUL,
                 "work_per_unit": w_kernel,
                 "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01)",
-                "valu_issue_utilisation_pmc": valu_util,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic_source": pmc_src,
+                "algorithmic_bytes_per_launch": BYTES_PER_VERIFY * n,
+                "pmc": {k: pmc["ssa_k_verify"].get(k) for k in ("SQ_INSTS_VALU", "valu_mad_share", "valu_issue_utilisation",
+                                                                  "duration_ms")} if pmc else None,
+            },
+            "roofline_hash": {
+                "bound": "valu", "kernel": "ssa_k_hash", "work_per_unit": W_HASH,
+                "achieved": (W_HASH * n / (k_hash_ms * 1e-3) if k_hash_ms > 0 else 0.0) / 1e9,
+                "peak": PEAK_FPMUL / 1e9, "unit": "GFp-mul/s",
+                "frac": (W_HASH * n / (k_hash_ms * 1e-3) if k_hash_ms > 0 else 0.0) / PEAK_FPMUL,
             },
             "roofline_hbm": {
                 "bound": "hbm",
@@ -276,45 +514,133 @@ def main():
             out["measured_fpmul_peak"] = str(exc)
 
         if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle as orc_mod
-            try:
-                orc_mod.build(native=True)
-                orc = orc_mod.Oracle(native=True)
-            except Exception:
-                orc = orc_mod.Oracle()
-            m = min(args.cpu_sample, n)
-            hs, hp, hm = sigs[:m].cpu().numpy(), pks[:m].cpu().numpy(), msgs[:m].cpu().numpy()
-            threads = orc.hw_threads()
-            tc = time.perf_counter()
-            st = orc.verify_many(hs, hp, hm, check_torsion=False, threads=threads)
-            dt = time.perf_counter() - tc
-            gpu_st = status[:m].cpu().numpy()
-            # status currently holds the torsion-on run; honest/corrupted verdicts coincide for these inputs
-            out["cpu_baseline"] = {
-                "value": m / dt, "unit": "verifications/s", "cores": threads, "kind": "port",
-                "sample": "first %d signatures of rank 0's batch, C restatement of the reference algorithm "
-                          "(oracle/schnorr_oracle.c, -O3 -march=native, OpenMP), verify_batch semantics" % m,
-                "agrees_with_gpu": bool((st == gpu_st).all()),
-            }
-            # the same restatement the way the reference runs it: one thread (it has no threading), per
-            # signature with the subgroup check, and its MSM-form verify_batch
-            m1 = min(1024, m)
-            tc = time.perf_counter()
-            orc.verify_many(hs[:m1], hp[:m1], hm[:m1], check_torsion=True, threads=1)
-            t_one = time.perf_counter() - tc
-            co = np.random.default_rng(11).integers(0, 256, size=(m1, 32), dtype=np.uint8)
-            co[:, 16:] = 0
-            tc = time.perf_counter()
-            verdict_cpu = orc.verify_batch_msm(hs[:m1], hp[:m1], hm[:m1], co, threads=1)
-            t_msm = time.perf_counter() - tc
-            out["cpu_baseline"]["single_thread"] = {
-                "signature_verify_per_sec": m1 / t_one, "verify_batch_msm_form_signatures_per_sec": m1 / t_msm,
-                "verify_batch_msm_form_verdict": verdict_cpu, "sample": "first %d signatures, 1 thread" % m1}
+            out["cpu_baseline"] = cpu_baseline(np, sigs, pks, msgs, status_batch_semantics, min(args.cpu_sample, n))
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.finish()
+
+
+def strong_leg(rk, eng, total):
+    """config 4: one batch of `total` signatures lives on rank 0; scatter vs broadcast; 3 timed verification steps"""
+    torch = rk.torch
+    from schnorr_sig_amd.sharding import shard_range
+    full = (None, None, None)
+    if rk.rank == 0:
+        s_, p_, m_, _ = gen_batch(torch, eng, rk.dev, total, 0x5C4E0224)
+        full = (s_, p_, m_)
+    (sb, pb, mb), broadcast_ms = distribute(rk, full, total, "broadcast")
+    del sb, pb, mb
+    (sigs, pks, msgs), scatter_ms = distribute(rk, full, total, "scatter")
+    sigs, pks, msgs = sigs.contiguous(), pks.contiguous(), msgs.contiguous()
+    del full
+    lo, hi = shard_range(total, rk.rank, rk.world)
+    n = hi - lo
+    status = torch.empty(n, dtype=torch.uint8, device=rk.dev)
+    nfail = torch.zeros(1, dtype=torch.int64, device=rk.dev)
+
+    def step():
+        eng.verify_many_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, status.data_ptr(),
+                               nfail.data_ptr(), check_torsion=False)
+        rk.all_reduce_sum(nfail)
+    step()
+    rk.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step()
+    rk.sync_all()
+    dt = rk.max_over_ranks(time.perf_counter() - t0) / 3
+    return {"workload": "config4: ONE batch of %d signatures on rank 0 -> %d contiguous shards" % (total, rk.world),
+            "scaling": "strong", "signatures_total": total, "ms_per_batch": dt * 1e3,
+            "verifications_per_sec": total / dt,
+            "scatter_ms": scatter_ms, "broadcast_ms": broadcast_ms,
+            "verifications_per_sec_including_scatter": total / (dt + scatter_ms * 1e-3),
+            "rejected": int(nfail.item())}
+
+
+def keyed_leg(torch, eng, dev, g, n, n_keys=64):
+    """validator-set workload: n signatures by n_keys signers, through a keyed context (subgroup check and the
+    per-key tables done once at ssa_keyset_create); Signature::verify semantics"""
+    sks = torch.randint(0, 256, (n_keys, 32), dtype=torch.uint8, device=dev, generator=g)
+    sks[:, 31] &= 0x3F
+    sks[:, 0] |= 1
+    idx = torch.randint(0, n_keys, (n,), dtype=torch.int32, device=dev, generator=g)
+    sk_rows = sks[idx.long()].contiguous()
+    nonces = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    nonces[:, 31] &= 0x3F
+    nonces[:, 0] |= 1
+    msgs = torch.randint(0, 256, (n, 80), dtype=torch.uint8, device=dev, generator=g)
+    pks = torch.empty((n, 96), dtype=torch.uint8, device=dev)
+    sigs = torch.empty((n, 81), dtype=torch.uint8, device=dev)
+    eng.keygen_sign_many_device(sk_rows.data_ptr(), nonces.data_ptr(), msgs.data_ptr(), n, 80, pks.data_ptr(),
+                                sigs.data_ptr())
+    eng.sync()
+    first = torch.stack([(idx == k).nonzero()[0, 0] for k in range(n_keys)])
+    key_rows = pks[first].contiguous()
+    t0 = time.perf_counter()
+    ks = eng.keyset_create_device(key_rows.data_ptr(), n_keys)
+    eng.sync()
+    create_ms = (time.perf_counter() - t0) * 1e3
+    status = torch.empty(n, dtype=torch.uint8, device=dev)
+    nfail = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        eng.verify_many_indexed_device(ks, idx.data_ptr(), sigs.data_ptr(), msgs.data_ptr(), n, 80,
+                                       status.data_ptr(), nfail.data_ptr())
+    step()
+    eng.sync()
+    eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step()
+    eng.sync()
+    dt = (time.perf_counter() - t0) / 3
+    eng.enable_timing(False)
+    k_ms, _ = eng.read_timing("ssa_k_verify_keyed")
+    rej = int(nfail.item())
+    eng.keyset_destroy(ks)
+    return {"workload": "%d signatures by %d signers (keyed context), Signature::verify semantics" % (n, n_keys),
+            "verifications_per_sec": n / dt, "ms_per_batch": dt * 1e3, "keyset_create_ms": create_ms,
+            "kernel_ms": k_ms, "rejected": rej,
+            "roofline_frac": (W_VERIFY_KEYED * n / (k_ms * 1e-3) / PEAK_FPMUL) if k_ms > 0 else None}
+
+
+def cpu_baseline(np, sigs, pks, msgs, gpu_status_batch_semantics, m):
+    """The C restatement (oracle/, test infrastructure) timed on this box's host cores on the first m
+    signatures of rank 0's batch -- the same semantics (verify_batch: no torsion check) as the timed GPU steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc_mod
+    try:
+        orc_mod.build(native=True)
+        orc = orc_mod.Oracle(native=True)
+    except Exception:
+        orc = orc_mod.Oracle()
+    hs, hp, hm = sigs[:m].cpu().numpy(), pks[:m].cpu().numpy(), msgs[:m].cpu().numpy()
+    threads = orc.hw_threads()
+    tc = time.perf_counter()
+    st = orc.verify_many(hs, hp, hm, check_torsion=False, threads=threads)
+    dt = time.perf_counter() - tc
+    gpu_st = gpu_status_batch_semantics[:m].cpu().numpy()
+    out = {
+        "value": m / dt, "unit": "verifications/s", "cores": threads, "kind": "port",
+        "sample": "first %d signatures of rank 0's batch, C restatement of the reference algorithm "
+                  "(oracle/schnorr_oracle.c, -O3 -march=native, OpenMP), verify_batch semantics "
+                  "(check_torsion off on both sides)" % m,
+        "agrees_with_gpu": bool((st == gpu_st).all()),
+    }
+    # the same restatement the way the reference runs it: one thread (it has no threading), per
+    # signature with the subgroup check, and its MSM-form verify_batch (SURVEY.md 8(d))
+    m1 = min(1024, m)
+    tc = time.perf_counter()
+    orc.verify_many(hs[:m1], hp[:m1], hm[:m1], check_torsion=True, threads=1)
+    t_one = time.perf_counter() - tc
+    co = np.random.default_rng(11).integers(0, 256, size=(m1, 32), dtype=np.uint8)
+    co[:, 16:] = 0
+    tc = time.perf_counter()
+    verdict_cpu = orc.verify_batch_msm(hs[:m1], hp[:m1], hm[:m1], co, threads=1)
+    t_msm = time.perf_counter() - tc
+    out["single_thread"] = {
+        "signature_verify_per_sec": m1 / t_one, "verify_batch_msm_form_signatures_per_sec": m1 / t_msm,
+        "verify_batch_msm_form_verdict": verdict_cpu, "sample": "first %d signatures, 1 thread" % m1}
+    return out
 
 
 if __name__ == "__main__":

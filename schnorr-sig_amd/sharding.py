@@ -49,7 +49,8 @@ def scatter_rows(full, n, row_bytes, rank, world, dist, device=None, src=0):
     """Input distribution for a batch that is resident on rank `src`: every rank receives its own
     contiguous shard of the (n, row_bytes) uint8 array, each shard crossing one link once (direct
     scatter; a broadcast of the whole array would move `world` times the bytes and is ring/per-link
-    bound on xGMI).  `full` is only read on rank `src`.  Ragged shards are padded to the largest."""
+    bound on xGMI).  `full` is only read on rank `src`.  Equal shards are sent straight out of `full`
+    (views, no staging copy); ragged shards are padded to the largest."""
     import torch
     lo, hi = shard_range(n, rank, world)
     if dist is None or world == 1:
@@ -59,11 +60,28 @@ def scatter_rows(full, n, row_bytes, rank, world, dist, device=None, src=0):
     out = torch.empty((width, row_bytes), dtype=torch.uint8, device=dev)
     chunks = None
     if rank == src:
-        chunks = []
-        for r in range(world):
-            a, b = shard_range(n, r, world)
-            c = torch.zeros((width, row_bytes), dtype=torch.uint8, device=dev)
-            c[: b - a] = full[a:b]
-            chunks.append(c)
+        if n % world == 0:
+            chunks = [full[r * width:(r + 1) * width] for r in range(world)]
+        else:
+            chunks = []
+            for r in range(world):
+                a, b = shard_range(n, r, world)
+                c = torch.zeros((width, row_bytes), dtype=torch.uint8, device=dev)
+                c[: b - a] = full[a:b]
+                chunks.append(c)
     dist.scatter(out, chunks, src=src)
     return out[: hi - lo]
+
+
+def broadcast_rows(full, n, row_bytes, rank, world, dist, device=None, src=0):
+    """The simpler distribution BASELINE.json's north_star names: broadcast the WHOLE (n, row_bytes) array
+    from rank `src`, every rank then slices its own contiguous shard.  Moves `world` times the bytes of
+    scatter_rows; kept as an option and timed beside it."""
+    import torch
+    lo, hi = shard_range(n, rank, world)
+    if dist is None or world == 1:
+        return full[lo:hi]
+    dev = device if device is not None else (full.device if full is not None else "cpu")
+    buf = full if rank == src else torch.empty((n, row_bytes), dtype=torch.uint8, device=dev)
+    dist.broadcast(buf, src=src)
+    return buf[lo:hi]

@@ -21,7 +21,8 @@ def _worker(rank, world, port, n, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import Oracle
-    from schnorr_sig_amd.sharding import aggregate_fail_count, batch_verdict, gather_status, scatter_rows, shard_range
+    from schnorr_sig_amd.sharding import (aggregate_fail_count, batch_verdict, broadcast_rows, gather_status,
+                                          scatter_rows, shard_range)
     orc = Oracle()
     rng = np.random.default_rng(77)     # every rank derives the same global batch
     sks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); sks[:, 31] &= 0x3F; sks[:, 0] |= 1
@@ -32,6 +33,12 @@ def _worker(rank, world, port, n, q):
     full = torch.from_numpy(msgs) if rank == 0 else None
     got = scatter_rows(full, n, 80, rank, world, dist)
     assert (got.numpy() == msgs[lo:hi]).all()
+    # ... or by broadcast of the whole array (north_star's variant; bench.py times both)
+    got_b = broadcast_rows(torch.from_numpy(msgs.copy()) if rank == 0 else None, n, 80, rank, world, dist)
+    assert (got_b.numpy() == msgs[lo:hi]).all()
+    # equal shards are sent straight out of the resident array (views)
+    even = scatter_rows(torch.from_numpy(msgs[:36].copy()) if rank == 0 else None, 36, 80, rank, world, dist)
+    assert (even.numpy() == msgs[:36][18 * rank:18 * (rank + 1)]).all()
     pks, sigs = orc.keygen_sign_many(sks[lo:hi], nonces[lo:hi], msgs[lo:hi], threads=2)
     bad_global = [3, n // 2, n - 1]
     for b in bad_global:
