@@ -73,19 +73,32 @@ extern "C" {
 #define SSA_FLAG_FORCE_COOP 4u    /* always the low-latency kernel (one wave per signature) */
 #define SSA_FLAG_CHECK_TORSION 1u /* Signature::verify semantics (src/signature.rs:182-184);
                                      off = verify_batch semantics (src/batch.rs has no check) */
+#define SSA_FLAG_SIG_FLAG_BYTE 8u /* verify_batch semantics for byte 48 of the signature: the reference decompresses R
+                                     with its flag byte (from_compressed(&sig.x).unwrap(), src/batch.rs:104), so a
+                                     signature only verifies for the R the flags select: wrong sort bit (bit 6) or an
+                                     infinity bit (bit 7) that does not match the recomputed R -> SSA_INVALID_SIGNATURE,
+                                     an undecodable flag byte -> SSA_MALFORMED (the reference panics).  Off =
+                                     Signature::verify, which ignores the byte (src/signature.rs:186) */
 
 typedef struct ssa_ctx ssa_ctx;
 
 /* Parameter blob (Rescue-Prime instance + generator), see schnorr-sig_amd/params/gen_params.py.
  *   char magic[8] = "SSAPARM1"; u32 n_rounds, rate_off; i32 cap_len_idx; u32 pad_mode,
  *   digest_off, flags; u64 mds[144]; u64 ark1[8][12]; u64 ark2[8][12]; u64 gen_x[6], gen_y[6]
- * params == NULL selects the built-in default blob. */
+ * params == NULL selects the built-in default blob -- the builder's own Rescue constants and generator, NOT
+ * upstream's (they live in un-vendored crates; DESIGN.md "parity unpinned"): such a context rejects every genuine
+ * toposware signature and ssa_ctx_uses_default_params() returns 1 for it.  tools/blob_from_upstream.py builds the
+ * blob from upstream's constants.  The generator is validated on the device (on the curve, [q]G == O):
+ * SSA_ERR_PARAMS otherwise. */
 int ssa_ctx_create(ssa_ctx **out, int device, const void *params, size_t params_len);
+/* 1 when the context was created from the built-in blob (parity with upstream unpinned), 0 for a caller-supplied one */
+int ssa_ctx_uses_default_params(const ssa_ctx *ctx);
 void ssa_ctx_destroy(ssa_ctx *ctx);
 const char *ssa_strerror(int rc);
 /* the built-in blob (SSA_PARAMS_LENGTH bytes) */
 const void *ssa_default_params(void);
-/* make the context issue its work on an existing hipStream_t (NULL = its own stream) */
+/* make the context issue its work on an existing hipStream_t.  NULL = back to the context's own (non-blocking)
+ * stream; to select the legacy null stream pass HIP's own handle for it, hipStreamLegacy (or hipStreamPerThread). */
 int ssa_ctx_set_stream(ssa_ctx *ctx, void *hip_stream);
 /* average duration (ms) of the `ssa_k_verify` launches since the last call, measured with
  * hipEvents on the context's stream when profiling is on; resets the statistics. */
@@ -112,10 +125,12 @@ int ssa_verify_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const
  * reference's MSM verdict on honest and on corrupted-but-well-formed inputs; divergence
  * classes are listed in DESIGN.md).  Returns SSA_OK, SSA_INVALID_SIGNATURE (or
  * SSA_INVALID_PUBLIC_KEY with SSA_FLAG_CHECK_TORSION, SSA_MALFORMED) -- the smallest
- * non-zero status present.  n == 0 returns SSA_OK like the reference. */
-int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
-                     const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
-                     uint32_t flags);
+ * non-zero status present.  n == 0 returns SSA_OK like the reference.  SSA_FLAG_SIG_FLAG_BYTE is always on
+ * here (the reference's verify_batch honours the flag byte); pk_inf as in ssa_verify_many: an identity key is a
+ * valid PublicKey (src/public.rs:95-101) and contributes nothing to the equation (src/batch.rs:106). */
+int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                     const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                     size_t n, uint32_t flags);
 
 /* verify_batch exactly as src/batch.rs:31-130: sum s_i R_i - sum (s_i h_i) P_i ?= [sum s_i e_i] G with
  * R_i decompressed from sig.x (flag byte honoured), a 2n-point bucket MSM on the GPU and an x-only
@@ -124,9 +139,9 @@ int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, cons
  * call with getrandom(2).  Returns SSA_OK, SSA_INVALID_SIGNATURE, or
  * SSA_MALFORMED where the reference panics (undecodable sig.x, src/batch.rs:67,104).  No torsion
  * check, like the reference.  n <= 2^25 per call. */
-int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
-                         const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
-                         const uint8_t *coeffs);
+int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                         const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                         size_t n, const uint8_t *coeffs);
 
 /* hash_message for n (R.x, pk, message) triples -> n x 32-byte digests */
 int ssa_hash_message_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks,
@@ -137,9 +152,14 @@ int ssa_hash_message_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks,
 int ssa_rescue_hash_many(ssa_ctx *ctx, const uint64_t *felts, uint32_t felts_per_row, size_t n,
                          uint64_t *digests_out);
 
-/* pk_i = [sk_i]G (affine, 96 B) and sig_i = sign(sk_i, nonce_i, msg_i).  Scalars are 32-byte
- * LE values reduced mod q; sk == 0 is rejected with SSA_ERR_ARG like PrivateKey::new
- * (src/private.rs:49-57). */
+/* pk_i = [sk_i]G (affine, 96 B) and sig_i = sign(sk_i, nonce_i, msg_i).  Secret keys and nonces are 32-byte LE
+ * CANONICAL scalars in [1, q): 0 and values >= q return SSA_ERR_ARG (PrivateKey::new / Scalar::random never
+ * produce them, src/private.rs:49-57).  Drawing them uniformly is the caller's job -- 64 random bytes reduced
+ * mod q, as the C++ and Python mirrors do; 32 random bytes reduced mod q are biased (2^256 / q ~ 2.08) and leak the
+ * key through the nonces.  The kernel is VARIABLE-TIME in the secrets (comb windows equal to zero are skipped and the
+ * table is indexed by secret windows), like the reference's *_vartime verification calls but unlike its signing:
+ * use it where timing side channels are out of scope (test-input generation, trusted hosts).
+ * The _device form cannot report errors per lane: non-canonical inputs are reduced mod q there. */
 int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces,
                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
                          size_t msg_len, size_t n, uint8_t *pks_out, uint8_t *sigs_out);
@@ -180,10 +200,32 @@ int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t
 /* coeff_bytes in 1..32: little-endian coefficient width (d_coeffs == NULL: the library draws 128-bit
  * coefficients as above); *d_verdict_out receives the status */
 int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
-                                const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
+                                const uint8_t *d_pk_inf, const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
                                 size_t msg_len, size_t n, const uint8_t *d_coeffs, uint32_t coeff_bytes,
                                 uint32_t *d_verdict_out);
 int ssa_ctx_sync(ssa_ctx *ctx);
+
+/* ---- keyed context: many signatures by few signers (validator sets) ---------------------------------
+ * A key set runs once per KEY what Signature::verify runs per signature on the key: canonical-limb and on-curve
+ * checks, the subgroup check [q]P == O (src/signature.rs:182-184) and the table of multiples the ladder needs.
+ * ssa_verify_many_indexed then verifies signature i against key key_idx[i] starting at the ladder.  Same
+ * statuses as ssa_verify_many (a key that failed its subgroup check gives SSA_INVALID_PUBLIC_KEY under
+ * SSA_FLAG_CHECK_TORSION; an index >= m gives SSA_MALFORMED).  A key set belongs to the context it was created
+ * on; destroy it before the context. */
+typedef struct ssa_keyset ssa_keyset;
+int ssa_keyset_create(ssa_ctx *ctx, const uint8_t *pks, const uint8_t *pk_inf, size_t m, ssa_keyset **out);
+int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t m,
+                             ssa_keyset **out);
+void ssa_keyset_destroy(ssa_keyset *ks);
+/* per-key status (m bytes): 0 usable, 1 not in the prime subgroup, 3 malformed */
+int ssa_keyset_status(ssa_keyset *ks, uint8_t *status_out);
+int ssa_verify_many_indexed(ssa_ctx *ctx, ssa_keyset *ks, const uint32_t *key_idx, const uint8_t *sigs,
+                            const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                            size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out);
+int ssa_verify_many_indexed_device(ssa_ctx *ctx, ssa_keyset *ks, const uint32_t *d_key_idx, const uint8_t *d_sigs,
+                                   const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
+                                   size_t msg_len, size_t n, uint32_t flags, uint8_t *d_status_out,
+                                   uint64_t *d_n_fail_out);
 
 /* ---- several GPUs of one node from a single process --------------------------------------------
  * The batch shards by signature (contiguous ranges, sizes differ by at most one) over the listed
@@ -196,6 +238,13 @@ int ssa_multi_verify_many(ssa_multi *m, const uint8_t *sigs, const uint8_t *pks,
                           const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
                           size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out);
 
+/* verify_batch exactly as src/batch.rs (ssa_verify_batch_msm) with the batch sharded over the devices: each device
+ * reduces its shard to one point and one scalar, device 0 adds the shards up (one point addition per shard), computes
+ * [sum s_i e_i]G and compares x coordinates.  coeffs: n x 32 bytes or NULL (every device draws its own). */
+int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                               const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                               size_t n, const uint8_t *coeffs);
+
 /* ---- arithmetic probes (unit parity with the oracle; not part of the reference API) --- */
 /* op: 0 = Fp6 mul, 1 = Fp6 sqr, 2 = Fp6 inv, 3 = point add (affine 12+12 -> 12 felts + inf),
  *     4 = scalar mul [k]P (k in a[0..4], P in b), 5 = Fp mul (a[0]*b[0]), 6 = Fp inv,
@@ -206,7 +255,9 @@ int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, 
 /* n_blocks 64-byte blocks of the ChaCha20 keystream the MSM coefficients come from (RFC 8439 known answers) */
 int ssa_debug_chacha20(ssa_ctx *ctx, const uint8_t key[32], const uint8_t nonce[12], uint32_t counter0,
                        size_t n_blocks, uint8_t *out);
-/* register-resident Fp-mul throughput probe: returns Fp multiplications per second; variants 10..12: dependent
+/* register-resident Fp-mul throughput probe: returns Fp multiplications per second (variants 0..2: fp_mul chains
+ * with 1/4/8 independent streams, 3: the lazy Fp6 product + square, 4 / 5: squaring chains with the four- / three-
+ * multiply square); variants 10..12: dependent
  * cooperative doublings / mixed additions / general additions per second (one wave) */
 int ssa_bench_fpmul(ssa_ctx *ctx, int variant, double *fpmul_per_s);
 

@@ -176,7 +176,9 @@ class Oracle:
         assert msgs.ndim == 2 and msgs.shape[0] == n
         return msgs, None, msgs.shape[1], msgs.shape[1]
 
-    def verify_many(self, sigs, pks, msgs, offsets=None, check_torsion=True, threads=0, pk_inf=None):
+    def verify_many(self, sigs, pks, msgs, offsets=None, check_torsion=True, threads=0, pk_inf=None,
+                    sig_flag_byte=False):
+        """sig_flag_byte: verify_batch's semantics for byte 48 of the signature (src/batch.rs:104)"""
         sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 81)
         pks = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, 96)
         n = sigs.shape[0]
@@ -185,7 +187,7 @@ class Oracle:
         st = np.zeros(n, np.uint8)
         self.lib.so_verify_many(_ptr(sigs, _u8p), _ptr(pks, _u8p), _ptr(inf, _u8p), _ptr(msgs, _u8p),
                                 _ptr(off, _u64p), C.c_size_t(stride), C.c_size_t(mlen), C.c_size_t(n),
-                                int(check_torsion), int(threads), _ptr(st, _u8p))
+                                int(bool(check_torsion)) | (8 if sig_flag_byte else 0), int(threads), _ptr(st, _u8p))
         return st
 
     def keygen_sign_many(self, sks, nonces, msgs, offsets=None, threads=0):
@@ -200,13 +202,14 @@ class Oracle:
                                      C.c_size_t(n), int(threads), _ptr(pks, _u8p), _ptr(sigs, _u8p))
         return pks, sigs
 
-    def verify_batch_msm(self, sigs, pks, msgs, coeffs, offsets=None, threads=0):
+    def verify_batch_msm(self, sigs, pks, msgs, coeffs, offsets=None, threads=0, pk_inf=None):
         sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 81)
         pks = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, 96)
         coeffs = np.ascontiguousarray(coeffs, dtype=np.uint8).reshape(-1, 32)
         n = sigs.shape[0]
         msgs, off, stride, mlen = self._msgs(msgs, offsets, n)
-        return int(self.lib.so_verify_batch_msm(_ptr(sigs, _u8p), _ptr(pks, _u8p), _ptr(msgs, _u8p),
+        inf = np.ascontiguousarray(pk_inf, dtype=np.uint8) if pk_inf is not None else None
+        return int(self.lib.so_verify_batch_msm(_ptr(sigs, _u8p), _ptr(pks, _u8p), _ptr(inf, _u8p), _ptr(msgs, _u8p),
                                                 _ptr(off, _u64p), C.c_size_t(stride), C.c_size_t(mlen),
                                                 C.c_size_t(n), _ptr(coeffs, _u8p), int(threads)))
 

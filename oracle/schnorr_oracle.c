@@ -58,6 +58,7 @@ static u64 fp_inv(u64 a) { return fp_pow(a, FP_P - 2); }
 
 /* ------------------------------------------------------------------ Fp6 = Fp[u]/(u^6-7) */
 typedef struct { u64 c[6]; } fp6;
+#define FP6_ZERO_INIT {{0, 0, 0, 0, 0, 0}}
 static const fp6 FP6_ZERO = {{0, 0, 0, 0, 0, 0}};
 static const fp6 FP6_ONE = {{1, 0, 0, 0, 0, 0}};
 
@@ -607,25 +608,40 @@ int so_sign(const uint8_t sk32[32], const uint8_t nonce32[32], const uint8_t pk9
     return 0;
 }
 
-/* Signature::verify, src/signature.rs:181-205 */
+/* Signature::verify, src/signature.rs:181-205.
+ * flags bit 0: the subgroup check (:182-184; off = verify_batch semantics, src/batch.rs has none)
+ * flags bit 3: verify_batch's treatment of the signature's flag byte: R is what
+ *              AffinePoint::from_compressed(&sig.x).unwrap() yields (src/batch.rs:104) -- None (undecodable flag
+ *              byte, x not on the curve) is the reference's panic -> SO_MALFORMED -- and the equation must hold
+ *              for that point, R == [h]P + [e]G, not only for its x */
 int so_verify(const uint8_t sig81[81], const uint8_t pk96[96], int pk_inf, const uint8_t *msg,
-              size_t len, int check_torsion) {
+              size_t len, int flags) {
     fp6 px, py, x_felt;
     if (!fp6_from_bytes48(pk96, &px) || !fp6_from_bytes48(pk96 + 48, &py)) return SO_MALFORMED;
+    if (!pk_inf && !pt_on_curve(px, py)) return SO_MALFORMED;      /* PublicKey's constructors never yield this */
     jpt p = j_from_affine(px.c, py.c, pk_inf);
-    if (check_torsion) {                                            /* :182-184 */
+    if (flags & 1) {                                                /* :182-184 */
         jpt t = j_mul(&SC_Q, &p);
         if (!j_is_id(&t)) return SO_INVALID_PUBLIC_KEY;
     }
     if (!fp6_from_bytes48(sig81, &x_felt)) return SO_MALFORMED;     /* :186 */
     sc256 e = sc_from_bytes(sig81 + 49);
     if (sc_geq(&e, &SC_Q)) return SO_MALFORMED;                     /* Scalar::from_bytes is_none */
+    uint8_t rdec[96];
+    int r_inf = 0;
+    if ((flags & 8) && !so_decompress(sig81, rdec, &r_inf)) return SO_MALFORMED;   /* src/batch.rs:104 */
     uint8_t h32[32];
     so_hash_message(sig81, pk96, msg, len, h32);                    /* :188 */
     sc256 h = sc_reduce256(sc_from_bytes(h32));                     /* :189-192 */
     jpt r = j_double_mul(&h, &p, &e);                               /* :196-198 */
     fp6 rx, ry;
-    j_to_affine(&r, &rx, &ry);
+    int finite = j_to_affine(&r, &rx, &ry);
+    if (flags & 8) {
+        if (r_inf || !finite) return (r_inf && !finite) ? SO_OK : SO_INVALID_SIGNATURE;
+        fp6 dy = FP6_ZERO_INIT;
+        fp6_from_bytes48(rdec + 48, &dy);
+        return (fp6_eq(rx, x_felt) && fp6_eq(ry, dy)) ? SO_OK : SO_INVALID_SIGNATURE;
+    }
     return fp6_eq(rx, x_felt) ? SO_OK : SO_INVALID_SIGNATURE;       /* :200-204 */
 }
 
@@ -649,7 +665,7 @@ int so_hw_threads(void) {
 
 void so_verify_many(const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                     const uint8_t *msgs, const u64 *off, size_t stride, size_t msg_len, size_t n,
-                    int check_torsion, int threads, uint8_t *status) {
+                    int flags, int threads, uint8_t *status) {
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
@@ -657,8 +673,7 @@ void so_verify_many(const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_i
     for (long i = 0; i < (long)n; i++) {
         size_t len;
         const uint8_t *m = msg_at(msgs, off, stride, msg_len, (size_t)i, &len);
-        status[i] = (uint8_t)so_verify(sigs + 81 * i, pks + 96 * i, pk_inf ? pk_inf[i] : 0, m, len,
-                                       check_torsion);
+        status[i] = (uint8_t)so_verify(sigs + 81 * i, pks + 96 * i, pk_inf ? pk_inf[i] : 0, m, len, flags);
     }
 }
 
@@ -679,8 +694,9 @@ void so_keygen_sign_many(const uint8_t *sks, const uint8_t *nonces, const uint8_
 }
 
 /* verify_batch, src/batch.rs:31-130: sum s_i R_i - sum (s_i h_i) P_i ?= [sum s_i e_i] G (x-only) */
-int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs, const u64 *off,
-                        size_t stride, size_t msg_len, size_t n, const uint8_t *coeffs, int threads) {
+int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf, const uint8_t *msgs,
+                        const u64 *off, size_t stride, size_t msg_len, size_t n, const uint8_t *coeffs,
+                        int threads) {
     sc256 lin = {{0, 0, 0, 0}};
     jpt left = J_ID;
     int bad = 0;
@@ -709,17 +725,24 @@ int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *
             sc256 h = sc_reduce256(sc_from_bytes(h32));             /* :71 */
             sc256 s = sc_reduce256(sc_from_bytes(coeffs + 32 * i)); /* :77 */
             sc256 e = sc_from_bytes(sig + 49);
-            sc256 se = sc_mulmod(&s, &e);                           /* :92-97 */
-            lin_l = sc_addmod(lin_l, &se);
+            const int p_inf = pk_inf && pk_inf[i];                  /* the identity is a valid PublicKey */
+            if (sc_geq(&e, &SC_Q) || (!p_inf && !pt_on_curve(px, py))) {
+                bad = 1;                                            /* not constructible in the reference */
+                continue;
+            }
             /* AffinePoint::from_compressed(&sig.x).unwrap(), :104 */
-            fp6 rhs = fp6_add(fp6_add(fp6_mul(fp6_sqr(x_felt), x_felt), x_felt), CURVE_B), ry;
-            if (!fp6_sqrt(rhs, &ry)) {
+            uint8_t rdec[96];
+            int r_inf = 0;
+            if (!so_decompress(sig, rdec, &r_inf)) {
                 bad = 1;
                 continue;
             }
-            if (fp6_lex_largest(ry) != ((sig[48] >> 6) & 1)) ry = fp6_neg(ry);
-            jpt rp = j_from_affine(x_felt.c, ry.c, 0);
-            jpt np = j_from_affine(px.c, py.c, 0);
+            sc256 se = sc_mulmod(&s, &e);                           /* :92-97 */
+            lin_l = sc_addmod(lin_l, &se);
+            fp6 ry = FP6_ZERO_INIT;
+            fp6_from_bytes48(rdec + 48, &ry);
+            jpt rp = j_from_affine(x_felt.c, ry.c, r_inf);
+            jpt np = j_from_affine(px.c, py.c, p_inf);
             np = j_neg(&np);                                        /* :106 */
             sc256 sh = sc_mulmod(&s, &h);                           /* :109-111 */
             jpt t1 = j_mul(&s, &rp), t2 = j_mul(&sh, &np);          /* :123 (MSM, naive) */

@@ -53,19 +53,20 @@ void so_scalar_from_digest(const uint8_t h32[32], uint8_t out32[32]);
 void so_keygen(const uint8_t sk32[32], uint8_t pk96[96], int *pk_inf);
 int so_sign(const uint8_t sk32[32], const uint8_t nonce32[32], const uint8_t pk96[96],
             const uint8_t *msg, size_t len, uint8_t sig81[81]);
+/* flags: bit 0 = subgroup check (Signature::verify), bit 3 = verify_batch's flag-byte semantics */
 int so_verify(const uint8_t sig81[81], const uint8_t pk96[96], int pk_inf, const uint8_t *msg,
-              size_t len, int check_torsion);
+              size_t len, int flags);
 /* n independent Signature::verify calls; msg i = msgs + off[i] .. off[i+1] (off != NULL) or
  * msgs + i*stride, length msg_len.  threads <= 0 -> all hardware threads. */
 void so_verify_many(const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                     const uint8_t *msgs, const uint64_t *off, size_t stride, size_t msg_len,
-                    size_t n, int check_torsion, int threads, uint8_t *status);
+                    size_t n, int flags, int threads, uint8_t *status);
 void so_keygen_sign_many(const uint8_t *sks, const uint8_t *nonces, const uint8_t *msgs,
                          const uint64_t *off, size_t stride, size_t msg_len, size_t n, int threads,
                          uint8_t *pks, uint8_t *sigs);
 /* verify_batch exactly as src/batch.rs: random-linear-combination + MSM, x-only compare.
  * coeffs = n x 32-byte canonical scalars standing in for Scalar::random(rng). */
-int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
+int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf, const uint8_t *msgs,
                         const uint64_t *off, size_t stride, size_t msg_len, size_t n,
                         const uint8_t *coeffs, int threads);
 int so_hw_threads(void);

@@ -36,6 +36,7 @@ OK, INVALID_PUBLIC_KEY, INVALID_SIGNATURE, MALFORMED = 0, 1, 2, 3
 FLAG_CHECK_TORSION = 1
 FLAG_FORCE_LANE = 2   # throughput kernels (one signature per lane) whatever the batch size
 FLAG_FORCE_COOP = 4   # low-latency kernel (one wave per signature) whatever the batch size
+FLAG_SIG_FLAG_BYTE = 8  # verify_batch's semantics for byte 48 of the signature (src/batch.rs:104)
 _MODE_FLAGS = {None: 0, "auto": 0, "lane": FLAG_FORCE_LANE, "coop": FLAG_FORCE_COOP}
 
 Q = 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
@@ -75,12 +76,13 @@ def _load():
         "ssa_strerror": (C.c_char_p, [i32]),
         "ssa_default_params": (vp, []),
         "ssa_ctx_set_stream": (i32, [vp, vp]),
+        "ssa_ctx_uses_default_params": (i32, [vp]),
         "ssa_ctx_sync": (i32, [vp]),
         "ssa_ctx_enable_timing": (i32, [vp, i32]),
         "ssa_ctx_read_timing": (i32, [vp, C.c_char_p, C.POINTER(C.c_double), u64p]),
         "ssa_verify": (i32, [vp, vp, vp, vp, sz, u32]),
         "ssa_verify_many": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
-        "ssa_verify_batch": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, u32]),
+        "ssa_verify_batch": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32]),
         "ssa_hash_message_many": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
         "ssa_rescue_hash_many": (i32, [vp, vp, u32, sz, vp]),
         "ssa_keygen_sign_many": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, vp]),
@@ -88,12 +90,19 @@ def _load():
         "ssa_hash_message_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
         "ssa_rescue_hash_many_device": (i32, [vp, vp, u32, sz, vp]),
         "ssa_keygen_sign_many_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, vp]),
-        "ssa_verify_batch_msm": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
-        "ssa_verify_batch_msm_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, vp, u32, vp]),
+        "ssa_verify_batch_msm": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp]),
+        "ssa_verify_batch_msm_device": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp, u32, vp]),
         "ssa_verify_keyed_many": (i32, [vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
+        "ssa_keyset_create": (i32, [vp, vp, vp, sz, C.POINTER(vp)]),
+        "ssa_keyset_create_device": (i32, [vp, vp, vp, sz, C.POINTER(vp)]),
+        "ssa_keyset_destroy": (None, [vp]),
+        "ssa_keyset_status": (i32, [vp, vp]),
+        "ssa_verify_many_indexed": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
+        "ssa_verify_many_indexed_device": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, vp]),
         "ssa_multi_create": (i32, [C.POINTER(vp), C.POINTER(i32), i32, vp, sz]),
         "ssa_multi_destroy": (None, [vp]),
         "ssa_multi_verify_many": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
+        "ssa_multi_verify_batch_msm": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp]),
         "ssa_decompress_many": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_decompress_many_device": (i32, [vp, vp, sz, vp, vp, vp]),
         "ssa_debug_arith": (i32, [vp, i32, vp, vp, sz, sz, sz, vp, sz]),
@@ -159,6 +168,10 @@ class Engine:
         except Exception:
             pass
 
+    def uses_default_params(self):
+        """True when the context runs the builder-default (unpinned) Rescue constants and generator."""
+        return bool(_check(_lib.ssa_ctx_uses_default_params(self._ctx), "ssa_ctx_uses_default_params"))
+
     @staticmethod
     def default_params():
         return C.string_at(_lib.ssa_default_params(), 2816)
@@ -174,9 +187,11 @@ class Engine:
         assert m.ndim == 2 and m.shape[0] == n, "dense messages must be an (n, len) array"
         return m, None, m.shape[1], m.shape[1]
 
-    def verify_many(self, sigs, pks, msgs, offsets=None, check_torsion=True, pk_inf=None, mode=None):
+    def verify_many(self, sigs, pks, msgs, offsets=None, check_torsion=True, pk_inf=None, mode=None,
+                    sig_flag_byte=False):
         """n x Signature::verify -> (status uint8[n], n_fail).  mode: None/"auto" (wave-per-signature
-        kernel for small batches, lane-per-signature kernels for large ones), "lane" or "coop"."""
+        kernel for small batches, lane-per-signature kernels for large ones), "lane" or "coop".
+        sig_flag_byte: honour byte 48 of the signature as verify_batch does (src/batch.rs:104)."""
         sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
         n = sigs.shape[0]
         assert pks.shape[0] == n
@@ -184,21 +199,23 @@ class Engine:
         inf = _np_u8(pk_inf) if pk_inf is not None else None
         status = np.full(n, 255, dtype=np.uint8)
         nfail = C.c_uint64(0)
-        flags = (FLAG_CHECK_TORSION if check_torsion else 0) | _MODE_FLAGS[mode]
+        flags = (FLAG_CHECK_TORSION if check_torsion else 0) | _MODE_FLAGS[mode] | \
+            (FLAG_SIG_FLAG_BYTE if sig_flag_byte else 0)
         _check(_lib.ssa_verify_many(self._ctx, _ptr(sigs), _ptr(pks), _ptr(inf), _ptr(m), _ptr(off), stride,
                                     mlen, n, flags, _ptr(status), C.byref(nfail)), "ssa_verify_many")
         return status, int(nfail.value)
 
-    def verify_batch_status(self, sigs, pks, msgs, offsets=None, check_torsion=False):
+    def verify_batch_status(self, sigs, pks, msgs, offsets=None, check_torsion=False, pk_inf=None):
         sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
         n = sigs.shape[0]
         if pks.shape[0] != n:
             raise MalformedInput("We should have the same number of signatures than public keys")
         m, off, stride, mlen = self._msg_args(msgs, offsets, n)
-        return _check(_lib.ssa_verify_batch(self._ctx, _ptr(sigs), _ptr(pks), _ptr(m), _ptr(off), stride, mlen,
-                                            n, FLAG_CHECK_TORSION if check_torsion else 0), "ssa_verify_batch")
+        inf = _np_u8(pk_inf) if pk_inf is not None else None
+        return _check(_lib.ssa_verify_batch(self._ctx, _ptr(sigs), _ptr(pks), _ptr(inf), _ptr(m), _ptr(off), stride,
+                                            mlen, n, FLAG_CHECK_TORSION if check_torsion else 0), "ssa_verify_batch")
 
-    def verify_batch_msm(self, sigs, pks, msgs, offsets=None, coeffs=None):
+    def verify_batch_msm(self, sigs, pks, msgs, offsets=None, coeffs=None, pk_inf=None):
         """verify_batch as the reference runs it (random linear combination + MSM); one status."""
         sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
         n = sigs.shape[0]
@@ -206,12 +223,13 @@ class Engine:
             raise MalformedInput("We should have the same number of signatures than public keys")
         m, off, stride, mlen = self._msg_args(msgs, offsets, n)
         c = _np_u8(coeffs, 32) if coeffs is not None else None
-        return _check(_lib.ssa_verify_batch_msm(self._ctx, _ptr(sigs), _ptr(pks), _ptr(m), _ptr(off), stride, mlen,
-                                                n, _ptr(c)), "ssa_verify_batch_msm")
+        inf = _np_u8(pk_inf) if pk_inf is not None else None
+        return _check(_lib.ssa_verify_batch_msm(self._ctx, _ptr(sigs), _ptr(pks), _ptr(inf), _ptr(m), _ptr(off),
+                                                stride, mlen, n, _ptr(c)), "ssa_verify_batch_msm")
 
     def verify_batch_msm_device(self, d_sigs, d_pks, d_msgs, n, msg_len, d_coeffs, coeff_bytes, d_verdict,
-                                msg_stride=None, d_offsets=0):
-        _check(_lib.ssa_verify_batch_msm_device(self._ctx, d_sigs, d_pks, d_msgs, d_offsets or None,
+                                msg_stride=None, d_offsets=0, d_pk_inf=0):
+        _check(_lib.ssa_verify_batch_msm_device(self._ctx, d_sigs, d_pks, d_pk_inf or None, d_msgs, d_offsets or None,
                                                 msg_stride if msg_stride is not None else msg_len, msg_len, n,
                                                 d_coeffs, coeff_bytes, d_verdict), "ssa_verify_batch_msm_device")
 
@@ -224,9 +242,13 @@ class Engine:
                                        _ptr(out)), "ssa_debug_chacha20")
         return out.tobytes()
 
-    def verify_one(self, sig81, pk96, message, check_torsion=True):
+    def verify_one(self, sig81, pk96, message, check_torsion=True, pk_is_identity=False):
         sig, pk = _np_u8(bytearray(sig81)), _np_u8(bytearray(pk96))
         msg = _np_u8(bytearray(bytes(message) + b"\0"))
+        if pk_is_identity:   # ssa_verify has no identity marker: one-element ssa_verify_many
+            st, _ = self.verify_many(sig, pk, msg, offsets=np.array([0, len(message)], np.uint64),
+                                     check_torsion=check_torsion, pk_inf=np.ones(1, np.uint8))
+            return int(st[0])
         return _check(_lib.ssa_verify(self._ctx, _ptr(sig), _ptr(pk), _ptr(msg), len(message),
                                       FLAG_CHECK_TORSION if check_torsion else 0), "ssa_verify")
 
@@ -280,6 +302,50 @@ class Engine:
                "ssa_decompress_many")
         return pks, inf, st
 
+    # ---- keyed context (many signatures by few signers) ---------------------------------
+    def keyset_create(self, pks, pk_inf=None):
+        """-> opaque key set handle: subgroup check and ladder tables done once per key"""
+        pks = _np_u8(pks, 96)
+        inf = _np_u8(pk_inf) if pk_inf is not None else None
+        ks = C.c_void_p()
+        _check(_lib.ssa_keyset_create(self._ctx, _ptr(pks), _ptr(inf), pks.shape[0], C.byref(ks)), "ssa_keyset_create")
+        return ks
+
+    def keyset_create_device(self, d_pks, m, d_pk_inf=0):
+        ks = C.c_void_p()
+        _check(_lib.ssa_keyset_create_device(self._ctx, d_pks, d_pk_inf or None, m, C.byref(ks)),
+               "ssa_keyset_create_device")
+        return ks
+
+    def keyset_destroy(self, ks):
+        _lib.ssa_keyset_destroy(ks)
+
+    def keyset_status(self, ks, m):
+        st = np.full(m, 255, dtype=np.uint8)
+        _check(_lib.ssa_keyset_status(ks, _ptr(st)), "ssa_keyset_status")
+        return st
+
+    def verify_many_indexed(self, ks, key_idx, sigs, msgs, offsets=None, check_torsion=True, sig_flag_byte=False):
+        """n x Signature::verify against key key_idx[i] of the key set -> (status uint8[n], n_fail)"""
+        sigs = _np_u8(sigs, 81)
+        n = sigs.shape[0]
+        idx = np.ascontiguousarray(key_idx, dtype=np.uint32)
+        assert idx.size == n
+        m, off, stride, mlen = self._msg_args(msgs, offsets, n)
+        status = np.full(n, 255, dtype=np.uint8)
+        nfail = C.c_uint64(0)
+        flags = (FLAG_CHECK_TORSION if check_torsion else 0) | (FLAG_SIG_FLAG_BYTE if sig_flag_byte else 0)
+        _check(_lib.ssa_verify_many_indexed(self._ctx, ks, _ptr(idx), _ptr(sigs), _ptr(m), _ptr(off), stride, mlen, n,
+                                            flags, _ptr(status), C.byref(nfail)), "ssa_verify_many_indexed")
+        return status, int(nfail.value)
+
+    def verify_many_indexed_device(self, ks, d_key_idx, d_sigs, d_msgs, n, msg_len, d_status, d_nfail, msg_stride=None,
+                                   d_offsets=0, check_torsion=True):
+        _check(_lib.ssa_verify_many_indexed_device(self._ctx, ks, d_key_idx, d_sigs, d_msgs, d_offsets or None,
+                                                   msg_stride if msg_stride is not None else msg_len, msg_len, n,
+                                                   FLAG_CHECK_TORSION if check_torsion else 0, d_status, d_nfail),
+               "ssa_verify_many_indexed_device")
+
     # ---- device-buffer entry points (raw device addresses, e.g. torch.Tensor.data_ptr()) ----
     def set_stream(self, hip_stream):
         _check(_lib.ssa_ctx_set_stream(self._ctx, C.c_void_p(hip_stream or 0)), "ssa_ctx_set_stream")
@@ -318,6 +384,20 @@ class Engine:
         _check(_lib.ssa_ctx_read_timing(self._ctx, kernel.encode(), C.byref(avg), C.byref(cnt)),
                "ssa_ctx_read_timing")
         return avg.value, int(cnt.value)
+
+    def host_path_probe(self, sigs_t, pks_t, msgs_t, n, reps=3):
+        """PCIe-inclusive rate of the host-buffer entry point ssa_verify_many (what a Rust shim binds): the
+        device tensors are copied to ordinary pageable host arrays first, then `reps` timed calls."""
+        import time
+        hs, hp, hm = (t[:n].cpu().numpy() for t in (sigs_t, pks_t, msgs_t))
+        st, nf = self.verify_many(hs, hp, hm, check_torsion=False, mode="lane")     # warm-up: workspaces
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            st, nf = self.verify_many(hs, hp, hm, check_torsion=False, mode="lane")
+        dt = (time.perf_counter() - t0) / reps
+        return {"entry_point": "ssa_verify_many (host buffers in pageable memory, pinned in place per call, "
+                               "uploads in chunks overlapped with the hash kernel)",
+                "ms_per_batch": dt * 1e3, "verifications_per_sec": n / dt, "rejected": int(nf)}
 
     # ---- probes --------------------------------------------------------------------------
     def debug_arith(self, op, a, b, out_cols):
@@ -372,6 +452,19 @@ class MultiEngine:
         return status, int(nfail.value)
 
 
+    def verify_batch_msm(self, sigs, pks, msgs, offsets=None, coeffs=None, pk_inf=None):
+        """verify_batch as the reference runs it, the batch sharded over the devices (one status)."""
+        sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
+        n = sigs.shape[0]
+        m = _np_u8(msgs)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64) if offsets is not None else None
+        stride = mlen = 0 if off is not None else m.shape[1]
+        inf = _np_u8(pk_inf) if pk_inf is not None else None
+        c = _np_u8(coeffs, 32) if coeffs is not None else None
+        return _check(_lib.ssa_multi_verify_batch_msm(self._m, _ptr(sigs), _ptr(pks), _ptr(inf), _ptr(m), _ptr(off),
+                                                      stride, mlen, n, _ptr(c)), "ssa_multi_verify_batch_msm")
+
+
 _default_engine = None
 
 
@@ -388,11 +481,12 @@ def default_engine():
 class PublicKey:
     """PublicKey(AffinePoint) (src/public.rs:24): 96 bytes affine x || y, canonical LE limbs."""
 
-    def __init__(self, affine96):
+    def __init__(self, affine96, is_identity=False):
         b = bytes(affine96)
         if len(b) != AFFINE_PUBLIC_KEY_LENGTH:
             raise ValueError("PublicKey needs 96 bytes of affine coordinates")
         self.affine = b
+        self.is_identity = bool(is_identity)   # AffinePoint::identity() is a valid key (src/public.rs:95-101)
 
     def verify_signature(self, signature, message):  # src/signature.rs:170-176
         return signature.verify(message, self)
@@ -407,13 +501,11 @@ class PublicKey:
         pks, inf, st = (engine or default_engine()).decompress_many(np.frombuffer(b, np.uint8))
         if st[0] != 0:
             return None
-        pk = cls(pks[0].tobytes())
-        pk.is_identity = bool(inf[0])
-        return pk
+        return cls(pks[0].tobytes(), is_identity=bool(inf[0]))
 
     def to_bytes(self):
         """PublicKey::to_bytes (src/public.rs:49-51): x || flag byte (formatting only, no arithmetic)."""
-        if getattr(self, "is_identity", False):
+        if self.is_identity:
             return bytes(48) + bytes([0x80])
         p = 2**64 - 2**32 + 1
         flag = 0
@@ -425,7 +517,7 @@ class PublicKey:
         return self.affine[:48] + bytes([flag])
 
     def __eq__(self, o):
-        return isinstance(o, PublicKey) and o.affine == self.affine
+        return isinstance(o, PublicKey) and o.affine == self.affine and o.is_identity == self.is_identity
 
 
 class PrivateKey:
@@ -469,7 +561,8 @@ class Signature:
 
     def verify(self, message, pkey, engine=None):
         """Ok -> None; otherwise raises SignatureError (src/signature.rs:181-205)."""
-        st = (engine or default_engine()).verify_one(self.bytes, pkey.affine, message, check_torsion=True)
+        st = (engine or default_engine()).verify_one(self.bytes, pkey.affine, message, check_torsion=True,
+                                                     pk_is_identity=pkey.is_identity)
         if st == OK:
             return None
         if st == INVALID_PUBLIC_KEY:
@@ -555,15 +648,16 @@ def verify_batch(signatures, public_keys, messages, rng=None, engine=None, msm=F
     eng = engine or default_engine()
     sigs = np.frombuffer(b"".join(s.bytes for s in signatures), np.uint8)
     pks = np.frombuffer(b"".join(p.affine for p in public_keys), np.uint8)
+    inf = np.array([1 if p.is_identity else 0 for p in public_keys], np.uint8)
     flat, off = pack_messages(messages)
     if msm:
         coeffs = None
         if rng is not None:
             coeffs = np.frombuffer(b"".join((int.from_bytes(rng(64), "little") % Q).to_bytes(32, "little")
                                             for _ in signatures), np.uint8)
-        st = eng.verify_batch_msm(sigs, pks, flat, offsets=off, coeffs=coeffs)
+        st = eng.verify_batch_msm(sigs, pks, flat, offsets=off, coeffs=coeffs, pk_inf=inf)
     else:
-        st = eng.verify_batch_status(sigs, pks, flat, offsets=off, check_torsion=False)
+        st = eng.verify_batch_status(sigs, pks, flat, offsets=off, check_torsion=False, pk_inf=inf)
     if st == OK:
         return None
     if st == MALFORMED:

@@ -96,7 +96,25 @@ SSA_DEV u64 fp_mul(u64 a, u64 b) {
     mul64x64(a, b, lo, hi);
     return fp_reduce128(lo, hi);
 }
+// a^2 with three multiplies instead of four: a = a0 + 2^32 a1, a^2 = a0^2 + 2^33 a0 a1 + 2^64 a1^2.
+//   u  = a0*a1 + (a0^2 >> 33)            (no overflow: (2^32-1)^2 + 2^31 < 2^64)
+//   lo = (a0^2 mod 2^33) | (u mod 2^31) << 33     (disjoint bits: no carry)
+//   hi = a1^2 + (u >> 31)                (no overflow)
+// Measured on MI355X (DESIGN.md, round 2 experiments): v_mad_u64_u32 issues about as fast as the
+// shift/merge instructions this trades it for, so the saving is small; kept because it is never slower.
+SSA_DEV u64 fp_sqr3(u64 a) {
+    const u32 a0 = lo32(a), a1 = hi32(a);
+    const u64 t0 = (u64)a0 * a0;
+    const u64 u = (u64)a0 * a1 + (t0 >> 33);
+    const u64 lo = (t0 & 0x1ffffffffULL) | (u << 33);
+    const u64 hi = (u64)a1 * a1 + (u >> 31);
+    return fp_reduce128(lo, hi);
+}
+#ifdef SSA_FP_SQR4
 SSA_DEV u64 fp_sqr(u64 a) { return fp_mul(a, a); }
+#else
+SSA_DEV u64 fp_sqr(u64 a) { return fp_sqr3(a); }
+#endif
 
 // a * k for a 32-bit constant k: two mads, 96-bit result
 SSA_DEV u64 fp_mul_small(u64 a, u32 k) {

@@ -204,6 +204,40 @@ SSA_DEV fp6 f6_frob(const fp6 &a) {
     return r;
 }
 
+// norm to Fp: N(a) = a * prod_{k=1..5} frob_k(a) (only c0 of the product is non-zero); *conj receives the product
+SSA_DEV u64 f6_norm(const fp6 &a, fp6 *conj = nullptr) {
+    fp6 t = f6_mul(f6_frob<1>(a), f6_frob<2>(a));
+    t = f6_mul(t, f6_frob<3>(a));
+    t = f6_mul(t, f6_frob<4>(a));
+    t = f6_mul(t, f6_frob<5>(a));
+    fp_acc s;
+    acc_init(s, a.c[0], t.c[0]);
+#pragma unroll
+    for (int i = 1; i < 6; i++) acc_mac(s, a.c[i], fp_mul_small(t.c[6 - i], 7u));
+    if (conj) *conj = t;
+    return acc_reduce(s);
+}
+// Euler's criterion in Fp: n^((p-1)/2), (p-1)/2 = 2^31 (2^32 - 1)
+SSA_DEV bool fp_is_square(u64 n) {
+    if (fp_is_zero(n)) return true;
+    u64 x = n;                                   // n^(2^32 - 1) by the 2^k - 1 ladder
+    u64 x2 = fp_mul(fp_sqr(x), x);
+    u64 x4 = fp_mul(fp_sqr(fp_sqr(x2)), x2);
+    u64 x8 = x4;
+    for (int i = 0; i < 4; i++) x8 = fp_sqr(x8);
+    x8 = fp_mul(x8, x4);
+    u64 x16 = x8;
+    for (int i = 0; i < 8; i++) x16 = fp_sqr(x16);
+    x16 = fp_mul(x16, x8);
+    u64 x32 = x16;
+    for (int i = 0; i < 16; i++) x32 = fp_sqr(x32);
+    x32 = fp_mul(x32, x16);
+    for (int i = 0; i < 31; i++) x32 = fp_sqr(x32);
+    return fp_canon(x32) == 1ull;
+}
+// a is a square in Fp6  <=>  its norm is a square in Fp (the norm maps Fp6* onto Fp* and squares onto squares)
+SSA_DEV bool f6_is_square(const fp6 &a) { return fp_is_square(f6_norm(a)); }
+
 // a^-1 = (prod_{k=1..5} frob_k(a)) / N(a), with N(a) = a * prod in Fp.  a != 0 required.
 SSA_DEV fp6 f6_inv(const fp6 &a) {
     fp6 t = f6_mul(f6_frob<1>(a), f6_frob<2>(a));

@@ -54,6 +54,9 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     } else {
         std::memcpy(&hp, k_default_params, sizeof hp);
     }
+    // the built-in blob is the builder's own instance (Rescue constants and generator are NOT upstream's: DESIGN.md
+    // "parity unpinned"); a context created from it says so (ssa_ctx_uses_default_params)
+    const bool is_default = std::memcmp(&hp, k_default_params, sizeof hp) == 0;
     if (int rc = validate_params(hp)) return rc;
     hp.flags = 0;  // derived flags are the library's, not the caller's
     bool small_mds = true;
@@ -62,16 +65,27 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     HIP_TRY(hipSetDevice(device));
     ssa_ctx *ctx = new ssa_ctx();
     ctx->device = device;
+    ctx->default_params = is_default;
     if (const char *cm = std::getenv("SSA_COOP_MAX_N"))
         ctx->coop_max_n = ctx->coop_max_n_torsion = (size_t)std::strtoull(cm, nullptr, 10);
     if (const char *vb = std::getenv("SSA_VERIFY_BLOCK")) {
         const int v = std::atoi(vb);
         if (v == 64 || v == 128 || v == 256) ctx->verify_block = (unsigned)v;
     }
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
+    if (const char *pc = std::getenv("SSA_PIPELINE_CHUNKS")) {
+        const int v = std::atoi(pc);
+        if (v >= 1 && v <= 8) ctx->pipeline_chunks = (unsigned)v;
+    }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
+    for (auto &ev : ctx->copy_done)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            ssa_ctx_destroy(ctx);
+            return SSA_ERR_HIP;
+        }
     ctx->stream = ctx->own_stream;
     if (hipMalloc((void **)&ctx->d_params, sizeof(DevParams)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_gtab, GTAB_ENTRIES * 12 * sizeof(u64)) != hipSuccess) {
@@ -83,16 +97,26 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
-    // the generator must be on the curve; checked on the device while building the comb table
     hipLaunchKernelGGL(ssa_k_gtable, dim3(grid_for(GTAB_ENTRIES, 256)), dim3(256), 0, ctx->stream,
                        ctx->d_params, ctx->d_gtab);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (hipGetLastError() != hipSuccess || ctx->ws_fail.reserve(64)) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
-    if (ctx->ws_fail.reserve(64)) {
+    // the generator must be a point of the prime-order subgroup: on the curve, [q]G == O (through the comb table
+    // just built), G != O -- otherwise every verification would run on some other curve or a small subgroup
+    unsigned gen_ok = 0;
+    hipLaunchKernelGGL(ssa_k_check_generator, dim3(1), dim3(64), 0, ctx->stream, ctx->d_params,
+                       (const u64 *)ctx->d_gtab, (unsigned *)ctx->ws_fail.p);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(&gen_ok, ctx->ws_fail.p, sizeof gen_ok, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
+    }
+    if (gen_ok != 1u) {
+        ssa_ctx_destroy(ctx);
+        return SSA_ERR_PARAMS;
     }
     *out = ctx;
     return 0;
@@ -116,9 +140,14 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+    for (auto &ev : ctx->copy_done)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
+
+extern "C" int ssa_ctx_uses_default_params(const ssa_ctx *ctx) { return ctx ? (ctx->default_params ? 1 : 0) : SSA_ERR_ARG; }
 
 extern "C" int ssa_ctx_set_stream(ssa_ctx *ctx, void *hip_stream) {
     if (!ctx) return SSA_ERR_ARG;
@@ -174,7 +203,7 @@ extern "C" int ssa_hash_message_many_device(ssa_ctx *ctx, const uint8_t *d_sigs,
     MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
     return timed_launch(ctx, "ssa_k_hash", [&] {
         hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
-                           d_sigs, d_pks, mv, n, (u64 *)nullptr, d_digests_out);
+                           d_sigs, d_pks, mv, n, (u64 *)nullptr, d_digests_out, (const u32 *)nullptr, 0u);
     });
 }
 
@@ -195,7 +224,7 @@ int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t
     MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
     return timed_launch(ctx, "ssa_k_hash", [&] {
         hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
-                           d_sigs, d_pks, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr);
+                           d_sigs, d_pks, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr, (const u32 *)nullptr, 0u);
     });
 }
 
@@ -237,7 +266,7 @@ static int verify_launch(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_p
     if (ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
     int rc = timed_launch(ctx, "ssa_k_hash", [&] {
         hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
-                           d_sigs, d_pks, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr);
+                           d_sigs, d_pks, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr, (const u32 *)nullptr, 0u);
     });
     if (rc) return rc;
     return timed_launch(ctx, "ssa_k_verify", [&] {
@@ -274,6 +303,95 @@ extern "C" int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compres
 }
 
 // ------------------------------------------------------------------ host entry points
+// Caller memory pinned in place for the duration of one call (hipHostRegister): the DMA engines then read it
+// directly and asynchronously -- an upload from pageable memory is staged by the runtime and does not overlap the
+// kernels (measured: DESIGN.md).  Never kept across calls: the caller may free or remap the range.
+struct PinnedRange {
+    void *p = nullptr;
+    bool on = false;
+    bool pin(const void *ptr, size_t bytes) {
+        if (!ptr || bytes == 0) return true;
+        if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        p = const_cast<void *>(ptr);
+        on = true;
+        return true;
+    }
+    ~PinnedRange() {
+        if (on) (void)hipHostUnregister(p);
+    }
+};
+
+// Large host-buffer batch: uploads in chunks on the copy stream, the challenge hashes of chunk c start as soon as
+// chunk c has arrived (they are 27 % of the work), one verification launch over the whole batch at the end --
+// the ladder kernel keeps its full-size grid, only the first chunk's upload is exposed.
+static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                 const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                                 size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out, bool *used) {
+    *used = false;
+    const size_t mb = msgs_bytes(msg_off, msg_stride, msg_len, n);
+    PinnedRange r_sigs, r_pks, r_msgs, r_inf, r_off, r_status;
+    if (!r_sigs.pin(sigs, n * 81) || !r_pks.pin(pks, n * 96) || !r_msgs.pin(msgs, mb) || !r_inf.pin(pk_inf, n) ||
+        !r_off.pin(msg_off, msg_off ? (n + 1) * sizeof(uint64_t) : 0) || !r_status.pin(status_out, n))
+        return 0;   // cannot pin (e.g. a read-only mapping): the caller falls back to the plain path
+    *used = true;
+    if (ctx->st_sigs.reserve(n * 81) || ctx->st_pks.reserve(n * 96) || ctx->st_msgs.reserve(mb + 16) ||
+        ctx->st_status.reserve(n + 16) || ctx->ws_h.reserve(n * 4 * sizeof(u64)) ||
+        ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64)))
+        return SSA_ERR_HIP;
+    const u8 *d_inf = nullptr;
+    const u64 *d_off = nullptr;
+    if (msg_off) {
+        for (size_t i = 0; i < n; i++)
+            if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > 0xffffffffull) return SSA_ERR_ARG;
+        if (ctx->st_off.reserve((n + 1) * sizeof(uint64_t))) return SSA_ERR_HIP;
+        HIP_TRY(hipMemcpyAsync(ctx->st_off.p, msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy_stream));
+        d_off = (const u64 *)ctx->st_off.p;
+    }
+    if (pk_inf) {
+        if (ctx->st_inf.reserve(n)) return SSA_ERR_HIP;
+        HIP_TRY(hipMemcpyAsync(ctx->st_inf.p, pk_inf, n, hipMemcpyHostToDevice, ctx->copy_stream));
+        d_inf = (const u8 *)ctx->st_inf.p;
+    }
+    unsigned long long *d_fail = (unsigned long long *)ctx->ws_fail.p;
+    HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), ctx->stream));
+    const unsigned chunks = ctx->pipeline_chunks;
+    u8 *d_sigs = (u8 *)ctx->st_sigs.p, *d_pks = (u8 *)ctx->st_pks.p, *d_msgs = (u8 *)ctx->st_msgs.p;
+    for (unsigned c = 0; c < chunks; c++) {
+        const size_t lo = n * c / chunks, hi = n * (c + 1) / chunks, cnt = hi - lo;
+        if (cnt == 0) continue;
+        HIP_TRY(hipMemcpyAsync(d_sigs + 81 * lo, sigs + 81 * lo, cnt * 81, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(hipMemcpyAsync(d_pks + 96 * lo, pks + 96 * lo, cnt * 96, hipMemcpyHostToDevice, ctx->copy_stream));
+        const size_t m_lo = msg_off ? (size_t)msg_off[lo] : lo * msg_stride;
+        const size_t m_hi = msg_off ? (size_t)msg_off[hi] : (hi == n ? mb : hi * msg_stride);
+        if (m_hi > m_lo)
+            HIP_TRY(hipMemcpyAsync(d_msgs + m_lo, msgs + m_lo, m_hi - m_lo, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(hipEventRecord(ctx->copy_done[c], ctx->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->copy_done[c], 0));
+        MsgView mv{msg_off ? d_msgs : d_msgs + lo * msg_stride, msg_off ? d_off + lo : nullptr, msg_stride, msg_len};
+        int rc = timed_launch(ctx, "ssa_k_hash", [&] {
+            hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(cnt, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                               (const u8 *)(d_sigs + 81 * lo), (const u8 *)(d_pks + 96 * lo), mv, cnt,
+                               (u64 *)ctx->ws_h.p + 4 * lo, (u8 *)nullptr, (const u32 *)nullptr, 0u);
+        });
+        if (rc) return rc;
+    }
+    int rc = timed_launch(ctx, "ssa_k_verify", [&] {
+        hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(n, ctx->verify_block)), dim3(ctx->verify_block), 0, ctx->stream,
+                           (const u8 *)d_sigs, (const u8 *)d_pks, d_inf, (const u64 *)ctx->ws_h.p,
+                           (const u64 *)ctx->d_gtab, (u64 *)ctx->ws_tab.p, n, flags, (u8 *)ctx->st_status.p, d_fail);
+    });
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(status_out, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long nf = 0;
+    HIP_TRY(hipMemcpyAsync(&nf, d_fail, sizeof nf, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_fail_out) *n_fail_out = nf;
+    return 0;
+}
+
 extern "C" int ssa_verify_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                                const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
                                size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,
@@ -283,6 +401,14 @@ extern "C" int ssa_verify_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t 
     if (n_fail_out) *n_fail_out = 0;
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(ctx->device));
+    const size_t coop_lim = (flags & SSA_FLAG_CHECK_TORSION) ? ctx->coop_max_n_torsion : ctx->coop_max_n;
+    const bool lane_kernels = !(flags & SSA_FLAG_FORCE_COOP) && ((flags & SSA_FLAG_FORCE_LANE) || n > coop_lim);
+    if (lane_kernels && n >= ctx->pipeline_min_n && ctx->pipeline_chunks > 1) {
+        bool used = false;
+        const int rc = verify_many_pipelined(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, flags,
+                                             status_out, n_fail_out, &used);
+        if (used) return rc;
+    }
     StagedInputs s;
     const void *p;
     if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;
@@ -307,20 +433,25 @@ extern "C" int ssa_verify_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t 
     return 0;
 }
 
-extern "C" int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
-                                const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
-                                uint32_t flags) {
+extern "C" int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                                size_t n, uint32_t flags) {
     if (n == 0) return ctx ? SSA_OK : SSA_ERR_ARG;  // empty batch verifies (src/batch.rs)
     std::vector<uint8_t> status(n);
     uint64_t nf = 0;
-    if (int rc = ssa_verify_many(ctx, sigs, pks, nullptr, msgs, msg_off, msg_stride, msg_len, n, flags,
-                                 status.data(), &nf))
+    // the reference's verify_batch decompresses R with its flag byte (src/batch.rs:104)
+    if (int rc = ssa_verify_many(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n,
+                                 flags | SSA_FLAG_SIG_FLAG_BYTE, status.data(), &nf))
         return rc;
     if (nf == 0) return SSA_OK;
-    int worst = SSA_MALFORMED + 1;
-    for (uint8_t s : status)
-        if (s != SSA_OK && s < worst) worst = s;
-    return worst;
+    // the reference panics on an undecodable input before it compares anything (src/batch.rs:67,104): SSA_MALFORMED
+    // dominates; then the subgroup check of SSA_FLAG_CHECK_TORSION (an extension: src/batch.rs has none)
+    bool any_pk = false;
+    for (uint8_t s : status) {
+        if (s == SSA_MALFORMED) return SSA_MALFORMED;
+        any_pk = any_pk || s == SSA_INVALID_PUBLIC_KEY;
+    }
+    return any_pk ? SSA_INVALID_PUBLIC_KEY : SSA_INVALID_SIGNATURE;
 }
 
 extern "C" int ssa_verify(ssa_ctx *ctx, const uint8_t sig[SSA_SIGNATURE_LENGTH],
@@ -377,18 +508,22 @@ extern "C" int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint
     if (!ctx || (n && (!sks || !nonces || !pks_out || !sigs_out))) return SSA_ERR_ARG;
     if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
     if (n == 0) return 0;
-    // PrivateKey::new never yields 0 (src/private.rs:49-57)
+    // secret keys and nonces are canonical non-zero scalars: PrivateKey::new / Scalar::random never yield 0 or a
+    // value >= q (src/private.rs:49-57); a caller that reduced 32 random bytes itself would hand over biased nonces
     static const uint8_t q_le[32] = {0xcf, 0xac, 0xd4, 0xae, 0x3e, 0x62, 0x43, 0xd4, 0x22, 0x77, 0x15,
                                      0x30, 0x23, 0xa7, 0x7a, 0x32, 0xb5, 0x37, 0x0a, 0x99, 0x0f, 0xbf,
                                      0x3f, 0x56, 0xd0, 0x22, 0x3f, 0x3b, 0x9b, 0x59, 0xf2, 0x7a};
-    for (size_t i = 0; i < n; i++) {
-        bool zero = true, is_q = true;
-        for (int k = 0; k < 32; k++) {
-            zero = zero && sks[32 * i + k] == 0;
-            is_q = is_q && sks[32 * i + k] == q_le[k];
+    auto canonical_nonzero = [](const uint8_t *v) {
+        bool zero = true;
+        int cmp = 0;   // sign of v - q, decided from the most significant byte down
+        for (int k = 31; k >= 0; k--) {
+            zero = zero && v[k] == 0;
+            if (cmp == 0 && v[k] != q_le[k]) cmp = v[k] < q_le[k] ? -1 : 1;
         }
-        if (zero || is_q) return SSA_ERR_ARG;
-    }
+        return !zero && cmp < 0;
+    };
+    for (size_t i = 0; i < n; i++)
+        if (!canonical_nonzero(sks + 32 * i) || !canonical_nonzero(nonces + 32 * i)) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     StagedInputs s;
     const void *p_sk, *p_nonce;
@@ -447,6 +582,125 @@ extern "C" int ssa_verify_keyed_many(ssa_ctx *ctx, const uint8_t *keyed, const u
     if (int rc = ssa_verify_many_device(ctx, (const u8 *)ctx->st_sigs.p, (const u8 *)ctx->st_pks.p,
                                         (const u8 *)ctx->st_inf.p, s.msgs, s.off, msg_stride, msg_len, n, flags,
                                         (u8 *)ctx->st_status.p, (uint64_t *)d_fail))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(status_out, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long nf = 0;
+    HIP_TRY(hipMemcpyAsync(&nf, d_fail, sizeof nf, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_fail_out) *n_fail_out = nf;
+    return 0;
+}
+
+// ------------------------------------------------------------------ keyed context
+struct ssa_keyset {
+    ssa_ctx *ctx = nullptr;
+    size_t m = 0;
+    DevBuf tab, status, pks;
+};
+
+extern "C" int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t m,
+                                        ssa_keyset **out) {
+    if (!ctx || !out || !d_pks || m == 0 || m > 0xffffffffull) return SSA_ERR_ARG;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ssa_keyset *ks = new ssa_keyset();
+    ks->ctx = ctx;
+    ks->m = m;
+    if (ks->tab.reserve(m * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64)) || ks->status.reserve(m + 16) ||
+        ks->pks.reserve(m * 96)) {
+        ssa_keyset_destroy(ks);
+        return SSA_ERR_HIP;
+    }
+    // the hash kernel reads the keys (x, y_0) through the index: keep a copy so that the caller's buffer can go
+    if (hipMemcpyAsync(ks->pks.p, d_pks, m * 96, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+        ssa_keyset_destroy(ks);
+        return SSA_ERR_HIP;
+    }
+    int rc = timed_launch(ctx, "ssa_k_keyset_build", [&] {
+        hipLaunchKernelGGL(ssa_k_keyset_build, dim3(grid_for(m, 256)), dim3(256), 0, ctx->stream,
+                           (const u8 *)ks->pks.p, d_pk_inf, m, (u64 *)ks->tab.p, (u8 *)ks->status.p);
+    });
+    if (rc != 0 || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        ssa_keyset_destroy(ks);
+        return rc ? rc : SSA_ERR_HIP;
+    }
+    *out = ks;
+    return 0;
+}
+
+extern "C" int ssa_keyset_create(ssa_ctx *ctx, const uint8_t *pks, const uint8_t *pk_inf, size_t m, ssa_keyset **out) {
+    if (!ctx || !out || !pks || m == 0) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const void *p_pks, *p_inf = nullptr;
+    if (int rc = stage_up(ctx, ctx->st_pks, pks, m * 96, &p_pks)) return rc;
+    if (pk_inf)
+        if (int rc = stage_up(ctx, ctx->st_inf, pk_inf, m, &p_inf)) return rc;
+    return ssa_keyset_create_device(ctx, (const u8 *)p_pks, (const u8 *)p_inf, m, out);
+}
+
+extern "C" void ssa_keyset_destroy(ssa_keyset *ks) {
+    if (!ks) return;
+    if (ks->ctx) {
+        (void)hipSetDevice(ks->ctx->device);
+        (void)hipStreamSynchronize(ks->ctx->stream);
+    }
+    ks->tab.release();
+    ks->status.release();
+    ks->pks.release();
+    delete ks;
+}
+
+extern "C" int ssa_keyset_status(ssa_keyset *ks, uint8_t *status_out) {
+    if (!ks || !status_out) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ks->ctx->device));
+    HIP_TRY(hipMemcpyAsync(status_out, ks->status.p, ks->m, hipMemcpyDeviceToHost, ks->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ks->ctx->stream));
+    return 0;
+}
+
+extern "C" int ssa_verify_many_indexed_device(ssa_ctx *ctx, ssa_keyset *ks, const uint32_t *d_key_idx,
+                                              const uint8_t *d_sigs, const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                              size_t msg_stride, size_t msg_len, size_t n, uint32_t flags,
+                                              uint8_t *d_status_out, uint64_t *d_n_fail_out) {
+    if (!ctx || !ks || ks->ctx != ctx || (n && (!d_key_idx || !d_sigs || !d_status_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long *d_fail = d_n_fail_out ? (unsigned long long *)d_n_fail_out
+                                              : (unsigned long long *)ctx->ws_fail.p;
+    HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), ctx->stream));
+    if (n == 0) return 0;
+    if (ctx->ws_h.reserve(n * 4 * sizeof(u64))) return SSA_ERR_HIP;
+    MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
+    int rc = timed_launch(ctx, "ssa_k_hash", [&] {
+        hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params, d_sigs,
+                           (const u8 *)ks->pks.p, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr, d_key_idx, (u32)ks->m);
+    });
+    if (rc) return rc;
+    return timed_launch(ctx, "ssa_k_verify_keyed", [&] {
+        hipLaunchKernelGGL(ssa_k_verify_keyed, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_sigs, d_key_idx,
+                           (const u64 *)ks->tab.p, (const u8 *)ks->status.p, (u32)ks->m, (const u64 *)ctx->ws_h.p,
+                           (const u64 *)ctx->d_gtab, n, flags, d_status_out, d_fail);
+    });
+}
+
+extern "C" int ssa_verify_many_indexed(ssa_ctx *ctx, ssa_keyset *ks, const uint32_t *key_idx, const uint8_t *sigs,
+                                       const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                                       size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out) {
+    if (!ctx || !ks || ks->ctx != ctx || (n && (!key_idx || !sigs || !status_out))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (n_fail_out) *n_fail_out = 0;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    StagedInputs s;
+    const void *p, *p_idx;
+    if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;
+    s.sigs = (const u8 *)p;
+    if (int rc = stage_up(ctx, ctx->st_aux, key_idx, n * sizeof(uint32_t), &p_idx)) return rc;
+    if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
+    if (ctx->st_status.reserve(n + 16)) return SSA_ERR_HIP;
+    unsigned long long *d_fail = (unsigned long long *)ctx->ws_fail.p;
+    if (int rc = ssa_verify_many_indexed_device(ctx, ks, (const uint32_t *)p_idx, s.sigs, s.msgs, s.off, msg_stride,
+                                                msg_len, n, flags, (u8 *)ctx->st_status.p, (uint64_t *)d_fail))
         return rc;
     HIP_TRY(hipMemcpyAsync(status_out, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
     unsigned long long nf = 0;
@@ -531,6 +785,47 @@ extern "C" int ssa_multi_verify_many(ssa_multi *m, const uint8_t *sigs, const ui
     return 0;
 }
 
+// verify_batch in its MSM form over several devices: every device runs the bucket MSM on its
+// contiguous shard and returns ONE point and ONE scalar; device 0 adds them up -- one Jacobian addition per shard --
+// computes [sum s_i e_i]G and compares x coordinates (src/batch.rs:98-100,123-129).  The only cross-device traffic
+// is 24 words per shard.
+extern "C" int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
+                                          size_t msg_len, size_t n, const uint8_t *coeffs) {
+    if (!m || m->ctxs.empty() || (n && (!sigs || !pks))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (n == 0) return SSA_OK;
+    const size_t world = m->ctxs.size();
+    std::vector<int> rcs(world, 0);
+    std::vector<uint64_t> parts(24 * world, 0);
+    std::vector<std::thread> threads;
+    const size_t base = n / world, rem = n % world;
+    for (size_t r = 0; r < world; r++) {
+        const size_t lo = r * base + (r < rem ? r : rem), cnt = base + (r < rem ? 1 : 0);
+        threads.emplace_back([&, r, lo, cnt] {
+            if (cnt == 0) return;
+            std::vector<uint64_t> off;
+            const uint8_t *mbase = msgs;
+            const uint64_t *offp = nullptr;
+            if (msg_off) {
+                off.resize(cnt + 1);
+                for (size_t k = 0; k <= cnt; k++) off[k] = msg_off[lo + k] - msg_off[lo];
+                mbase = msgs + msg_off[lo];
+                offp = off.data();
+            } else {
+                mbase = msgs ? msgs + lo * msg_stride : nullptr;
+            }
+            rcs[r] = ssa_internal_msm_partial(m->ctxs[r], sigs + 81 * lo, pks + 96 * lo, pk_inf ? pk_inf + lo : nullptr,
+                                              mbase, offp, msg_stride, msg_len, cnt, coeffs ? coeffs + 32 * lo : nullptr,
+                                              &parts[24 * r]);
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (size_t r = 0; r < world; r++)
+        if (rcs[r] != 0) return rcs[r];
+    return ssa_internal_msm_combine(m->ctxs[0], parts.data(), world);
+}
+
 // ------------------------------------------------------------------ probes
 extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                                size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {
@@ -609,6 +904,16 @@ extern "C" int ssa_bench_fpmul(ssa_ctx *ctx, int variant, double *fpmul_per_s) {
                 hipLaunchKernelGGL(ssa_k_fpmul_bench<8>, dim3(blocks), dim3(threads), 0, ctx->stream,
                                    (u64 *)ctx->st_aux.p, 0x1234567ull, iters);
                 muls_per_thread = 2.0 * 8 * iters;
+                break;
+            case 4:
+                hipLaunchKernelGGL(ssa_k_fpsqr_bench<0>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                                   (u64 *)ctx->st_aux.p, 0x1234567ull, iters / 4);
+                muls_per_thread = 16.0 * (iters / 4);
+                break;
+            case 5:
+                hipLaunchKernelGGL(ssa_k_fpsqr_bench<1>, dim3(blocks), dim3(threads), 0, ctx->stream,
+                                   (u64 *)ctx->st_aux.p, 0x1234567ull, iters / 4);
+                muls_per_thread = 16.0 * (iters / 4);
                 break;
             default:
                 hipLaunchKernelGGL(ssa_k_f6mul_bench, dim3(blocks), dim3(threads), 0, ctx->stream,

@@ -595,7 +595,7 @@ COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane, int ws = 0) {
 // workgroup barriers.  Check order as in the reference (src/signature.rs:181-205): key decoding,
 // subgroup check (InvalidPublicKey), then the signature's x (the reference panics: SSA_MALFORMED).
 struct CoopShared {
-    u32 ok_pk, ok_sig, tors_bad, eq;
+    u32 ok_pk, ok_sig, tors_bad, eq, x_bad;
     u64 h[4];
 };
 
@@ -622,11 +622,16 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
         }
         pk_ok = __all(pk_ok);
         sig_ok = __all(sig_ok) && !sc_geq_q(e);
+        if ((flags & VF_SIG_FLAG_BYTE) && sig_ok) {
+            const bool x0 = __all(lane < 6 ? ld_u64_le(sig + 8 * lane) == 0ull : true);
+            sig_ok = sig_flag_precheck(sig[48], x0) == ST_OK;
+        }
         if (lane == 0) {
             sh.ok_pk = pk_ok;
             sh.ok_sig = sig_ok;
             sh.tors_bad = 0;
             sh.eq = 0;
+            sh.x_bad = 0;
         }
     }
     __syncthreads();
@@ -681,12 +686,42 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
                 }
             }
             bool eq;
-            if (coop_is_zero(L, AZ, lane, ws)) {
-                eq = coop_is_zero(L, SX, lane, ws);                       // the identity's x is taken as 0
+            const bool r_inf = coop_is_zero(L, AZ, lane, ws);
+            const u32 fbyte = sig[48];
+            if ((flags & VF_SIG_FLAG_BYTE) && (fbyte & 0x80u)) {
+                eq = r_inf;                                               // R decodes to the identity
+            } else if (r_inf) {
+                eq = !(flags & VF_SIG_FLAG_BYTE) && coop_is_zero(L, SX, lane, ws);   // the identity's x is taken as 0
             } else {
                 coop_mul(L, T0, AZ, AZ, lane, ws);
                 coop_mul(L, T0, SX, T0, lane, ws);
                 eq = coop_eq(L, AX, T0, lane, ws);                        // X == x * Z^2, src/signature.rs:200
+                if (eq && (flags & VF_SIG_FLAG_BYTE)) {                   // the y the flag byte selects (src/batch.rs:104)
+                    coop_inv(L, T0, AZ, T0 + 1, T0 + 2, T0 + 3, lane, ws);
+                    coop_mul(L, T0 + 1, T0, T0, lane, ws);
+                    coop_mul(L, T0 + 1, T0 + 1, T0, lane, ws);
+                    coop_mul(L, T0 + 1, AY, T0 + 1, lane, ws);            // y = Y / Z^3
+                    fp6 y;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) y.c[c] = L.slot[T0 + 1][c];
+                    eq = f6_lex_largest(y) == ((fbyte & 0x40u) != 0);
+                }
+            }
+            if ((flags & VF_SIG_FLAG_BYTE) && !eq && !(fbyte & 0x80u)) {
+                // an x with no curve point (x^3 + x + u + 395 a non-square: its norm is a non-residue of Fp):
+                // from_compressed is None and the reference panics
+                coop_mul(L, T0, SX, SX, lane, ws);
+                coop_mul(L, T0, T0, SX, lane, ws);
+                coop_add(L, T0, T0, SX, lane, ws);
+                if (lane < 12 && (lane % 6u) < 2u) {
+                    const u64 add = (lane % 6u) == 0 ? 395ull : 1ull;
+                    L.slot[T0][lane] = fp_add(L.slot[T0][lane], lane < 6 ? add : 7ull * add);
+                }
+                coop_sync();
+                if (!coop_is_zero(L, T0, lane, ws)) {
+                    coop_inv(L, T0 + 1, T0, T0 + 2, T0 + 3, T0 + 4, lane, ws);
+                    if (!fp_is_square(L.slot[T0 + 4][0]) && lane == 0) sh.x_bad = 1;
+                }
             }
             if (lane == 0) sh.eq = eq;
         }
@@ -694,7 +729,7 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
     __syncthreads();
     if (!sh.ok_pk) return ST_MALFORMED;
     if ((flags & 1u) && sh.tors_bad) return ST_INVALID_PK;
-    if (!sh.ok_sig) return ST_MALFORMED;
+    if (!sh.ok_sig || sh.x_bad) return ST_MALFORMED;
     return sh.eq ? ST_OK : ST_INVALID_SIG;
 }
 

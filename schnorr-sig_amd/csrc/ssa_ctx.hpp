@@ -15,12 +15,18 @@
 
 using namespace ssa;
 
+// a library does not write to stderr on its own: the failing call is reported only when SSA_DEBUG is set
+static inline bool ssa_debug_enabled() {
+    static const bool on = std::getenv("SSA_DEBUG") != nullptr;
+    return on;
+}
 #define HIP_TRY(expr)                                                                    \
     do {                                                                                 \
         hipError_t err__ = (expr);                                                       \
         if (err__ != hipSuccess) {                                                       \
-            std::fprintf(stderr, "[schnorr_sig_amd] %s failed: %s (%s:%d)\n", #expr,     \
-                         hipGetErrorString(err__), __FILE__, __LINE__);                  \
+            if (ssa_debug_enabled())                                                     \
+                std::fprintf(stderr, "[schnorr_sig_amd] %s failed: %s (%s:%d)\n", #expr, \
+                             hipGetErrorString(err__), __FILE__, __LINE__);              \
             return SSA_ERR_HIP;                                                          \
         }                                                                                \
     } while (0)
@@ -53,6 +59,10 @@ struct ssa_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;        // uploads of the host-buffer entry points, overlapped with the kernels
+    hipEvent_t copy_done[8] = {};             // one per upload chunk
+    size_t pipeline_min_n = 1 << 17;          // host-buffer batches from this size on are uploaded in chunks
+    unsigned pipeline_chunks = 4;             // SSA_PIPELINE_CHUNKS overrides (1 = off)
     DevParams *d_params = nullptr;
     u64 *d_gtab = nullptr;
     DevBuf ws_h, ws_tab, ws_fail;
@@ -62,6 +72,7 @@ struct ssa_ctx {
     DevBuf msm_points, msm_scalars, msm_keys, msm_vals, msm_keys2, msm_vals2, msm_sort_tmp, msm_bounds,
         msm_buckets, msm_chunks, msm_windows, msm_partials, msm_flags, st_coeffs, msm_cnt, msm_cnt2, msm_ids, msm_ids2;
     bool timing = false;
+    bool default_params = false;   // created from the built-in (unpinned) blob
     // batches up to these sizes take the cooperative (waves-per-signature) kernel: measured crossovers without /
     // with the subgroup check (tools/mode_crossover.py); SSA_COOP_MAX_N overrides both
     size_t coop_max_n = 10240, coop_max_n_torsion = 14336;
@@ -145,3 +156,10 @@ static inline int stage_msgs(ssa_ctx *ctx, const uint8_t *msgs, const uint64_t *
 // defined in ssa_api.hip: hash_message + Scalar::from_bits_vartime for n signatures into ctx->ws_h
 int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
                               const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n);
+
+// defined in ssa_msm.hip: one shard's partial sums of the MSM-form batch (host buffers in, 24 words out), and the
+// combination of k shards on one device (returns a status)
+int ssa_internal_msm_partial(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                             const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                             const uint8_t *coeffs, uint64_t out24[24]);
+int ssa_internal_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k);

@@ -122,15 +122,18 @@ SSA_DEV void hash_message_lane(u64 *A, u64 *B, const DevParams *__restrict__ prm
 __global__ void __launch_bounds__(256)
 ssa_k_hash(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs,
            const u8 *__restrict__ pks, MsgView mv, size_t n, u64 *__restrict__ h_out,
-           u8 *__restrict__ digest_out) {
+           u8 *__restrict__ digest_out, const u32 *__restrict__ key_idx, u32 n_keys) {
     __shared__ u64 lds[RS_LDS_U64];
     u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.cuh)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool ok = true;
+    // keyed context: the signer's key is row key_idx[i] of the key set (an index out of range hashes row 0; the
+    // verification kernel reports it)
+    const size_t prow = key_idx ? (size_t)(key_idx[i] < n_keys ? key_idx[i] : 0u) : i;
     const fp6 rx = ld_fp6(sigs + 81 * i, ok);
-    const fp6 px = ld_fp6(pks + 96 * i, ok);
-    const u64 py0 = ld_u64_le(pks + 96 * i + 48);
+    const fp6 px = ld_fp6(pks + 96 * prow, ok);
+    const u64 py0 = ld_u64_le(pks + 96 * prow + 48);
     u32 len;
     const u8 *m = msg_ptr(mv, i, len);
     u64 d[4];
@@ -335,6 +338,31 @@ SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e) 
     return acc;
 }
 
+// CompressedPoint flag byte of a signature's x under verify_batch semantics (SSA_FLAG_SIG_FLAG_BYTE): the
+// reference decompresses R with it (AffinePoint::from_compressed(&sig.x).unwrap(), src/batch.rs:104), so the batch
+// equation only holds for the R the flag selects.  0 = well-formed, 3 = from_compressed is None (the reference panics).
+SSA_DEV u32 sig_flag_precheck(u32 flag, bool x_is_zero) {
+    if (flag & 0x3fu) return ST_MALFORMED;
+    if ((flag & 0x80u) && (!x_is_zero || (flag & 0x40u))) return ST_MALFORMED;
+    return ST_OK;
+}
+// sort bit of the affine y of a finite Jacobian point (cold: one Fp6 inversion)
+SSA_FN bool jac_y_lex_largest(const jac &p) {
+    const fp6 zi = f6_inv(p.Z);
+    const fp6 y = f6_mul(p.Y, f6_mul(zi, f6_sqr(zi)));
+    return f6_lex_largest(y);
+}
+
+// x is the abscissa of a curve point: x^3 + x + (u + 395) is a square (cold: rejected lanes of the flag-byte mode)
+SSA_FN bool x_on_curve(const fp6 &x) {
+    fp6 rhs = f6_add(f6_mul(f6_sqr(x), x), x);
+    rhs.c[0] = fp_add(rhs.c[0], 395ull);
+    rhs.c[1] = fp_add(rhs.c[1], 1ull);
+    return f6_is_square(rhs);
+}
+
+constexpr u32 VF_CHECK_TORSION = 1u, VF_SIG_FLAG_BYTE = 8u;
+
 #ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256, 2)
 ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
@@ -350,6 +378,8 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
         const fp6 xs = ld_fp6(sigs + 81 * i, ok_sig);
         const sc256 e = ld_sc(sigs + 81 * i + 49);
         ok_sig = ok_sig && !sc_geq_q(e);
+        const u32 fbyte = sigs[81 * i + 48];
+        if ((flags & VF_SIG_FLAG_BYTE) && ok_sig) ok_sig = sig_flag_precheck(fbyte, f6_is_zero(xs)) == ST_OK;
         aff P;
         P.x = ld_fp6(pks + 96 * i, ok);
         P.y = ld_fp6(pks + 96 * i + 48, ok);
@@ -367,7 +397,7 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
             for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
             jac r = jac_identity();
 #pragma unroll 1
-            for (int pass = (flags & 1u) ? 0 : 1; pass < 2; pass++) {
+            for (int pass = (flags & VF_CHECK_TORSION) ? 0 : 1; pass < 2; pass++) {
                 if (pass == 1 && !ok_sig) {
                     status = ST_MALFORMED;
                     break;
@@ -387,16 +417,107 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
                 r = add_base_mul(r, gtab, e);               // + [e]G, :196-198
                 // r.get_x() == x_felt (:200): X == x * Z^2; the identity's x is taken as 0
                 bool eq;
-                if (jac_is_identity(r))
+                if (flags & VF_SIG_FLAG_BYTE) {
+                    // verify_batch semantics: R is the point sig.x's flag byte selects (src/batch.rs:104)
+                    if (fbyte & 0x80u) {
+                        eq = jac_is_identity(r);
+                    } else {
+                        eq = !jac_is_identity(r) && f6_eq(r.X, f6_mul(xs, f6_sqr(r.Z)));
+                        if (eq) eq = jac_y_lex_largest(r) == ((fbyte & 0x40u) != 0);
+                        // an x with no curve point: from_compressed is None, the reference panics
+                        else if (!x_on_curve(xs)) ok_sig = false;
+                    }
+                } else if (jac_is_identity(r)) {
                     eq = f6_is_zero(xs);
-                else
+                } else {
                     eq = f6_eq(r.X, f6_mul(xs, f6_sqr(r.Z)));
-                status = eq ? ST_OK : ST_INVALID_SIG;
+                }
+                status = eq ? ST_OK : (ok_sig ? ST_INVALID_SIG : ST_MALFORMED);
             }
         }
         status_out[i] = (u8)status;
     }
     // aggregate verdict: one ballot + one atomic per wave
+    const unsigned long long bad = __ballot(status != ST_OK);
+    if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(n_fail, (unsigned long long)__popcll(bad));
+}
+#endif  // SSA_NO_KERNELS
+
+// ------------------------------------------------------------------------------------------
+// Keyed context (repeated public keys: validator sets; the reference's own batch test reuses keys,
+// src/batch.rs:152-175).  ssa_k_keyset_build runs ONCE per key what ssa_k_verify runs per signature: limb and
+// curve checks, the subgroup check [q]P == O (src/signature.rs:182-184) and the affine table 1P..8P.
+// ssa_k_verify_keyed then starts at the ladder: no table build, no [q]P pass.
+//   key_status: 0 usable, 1 not in the prime subgroup (InvalidPublicKey), 3 malformed
+#ifndef SSA_NO_KERNELS
+__global__ void __launch_bounds__(256, 2)
+ssa_k_keyset_build(const u8 *__restrict__ pks, const u8 *__restrict__ pk_inf, size_t m, u64 *__restrict__ key_tab,
+                   u8 *__restrict__ key_status) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    bool ok = true;
+    aff P;
+    P.x = ld_fp6(pks + 96 * i, ok);
+    P.y = ld_fp6(pks + 96 * i + 48, ok);
+    const bool inf = pk_inf && pk_inf[i];
+    if (ok && !inf) ok = aff_on_curve(P);
+    u32 st = ST_MALFORMED;
+    if (ok) {
+        u64 *tab = key_tab + i * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64);
+        build_ptab(tab, P, inf);
+        sc256 q;
+#pragma unroll
+        for (int j = 0; j < 4; j++) q.w[j] = SC_Q(j);
+        st = jac_is_identity(mul_ptab(tab, q)) ? ST_OK : ST_INVALID_PK;
+    }
+    key_status[i] = (u8)st;
+}
+
+__global__ void __launch_bounds__(256, 2)
+ssa_k_verify_keyed(const u8 *__restrict__ sigs, const u32 *__restrict__ key_idx, const u64 *__restrict__ key_tab,
+                   const u8 *__restrict__ key_status, u32 n_keys, const u64 *__restrict__ h_in,
+                   const u64 *__restrict__ gtab, size_t n, u32 flags, u8 *__restrict__ status_out,
+                   unsigned long long *__restrict__ n_fail) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 status = ST_OK;
+    if (i < n) {
+        bool ok_sig = true;
+        const fp6 xs = ld_fp6(sigs + 81 * i, ok_sig);
+        const sc256 e = ld_sc(sigs + 81 * i + 49);
+        ok_sig = ok_sig && !sc_geq_q(e);
+        const u32 fbyte = sigs[81 * i + 48];
+        if ((flags & VF_SIG_FLAG_BYTE) && ok_sig) ok_sig = sig_flag_precheck(fbyte, f6_is_zero(xs)) == ST_OK;
+        const u32 k = key_idx[i];
+        const u32 ks = k < n_keys ? (u32)key_status[k] : ST_MALFORMED;
+        // the order of Signature::verify: the key first (src/signature.rs:182), then the signature's x (:186)
+        if (ks == ST_MALFORMED) status = ST_MALFORMED;
+        else if (ks == ST_INVALID_PK && (flags & VF_CHECK_TORSION)) status = ST_INVALID_PK;
+        else if (!ok_sig) status = ST_MALFORMED;
+        if (status == ST_OK) {
+            const u64 *tab = key_tab + (size_t)k * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64);
+            sc256 h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) h.w[j] = h_in[4 * i + j];
+            jac r = mul_ptab(tab, h);
+            r = add_base_mul(r, gtab, e);
+            bool eq;
+            if (flags & VF_SIG_FLAG_BYTE) {
+                if (fbyte & 0x80u) {
+                    eq = jac_is_identity(r);
+                } else {
+                    eq = !jac_is_identity(r) && f6_eq(r.X, f6_mul(xs, f6_sqr(r.Z)));
+                    if (eq) eq = jac_y_lex_largest(r) == ((fbyte & 0x40u) != 0);
+                    else if (!x_on_curve(xs)) ok_sig = false;
+                }
+            } else if (jac_is_identity(r)) {
+                eq = f6_is_zero(xs);
+            } else {
+                eq = f6_eq(r.X, f6_mul(xs, f6_sqr(r.Z)));
+            }
+            status = eq ? ST_OK : (ok_sig ? ST_INVALID_SIG : ST_MALFORMED);
+        }
+        status_out[i] = (u8)status;
+    }
     const unsigned long long bad = __ballot(status != ST_OK);
     if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(n_fail, (unsigned long long)__popcll(bad));
 }
@@ -434,8 +555,34 @@ ssa_k_gtable(const DevParams *__restrict__ prm, u64 *__restrict__ gtab) {
 }
 #endif  // SSA_NO_KERNELS
 
+// out[0] = 1 when the blob's generator is a point of the prime-order subgroup: on the curve (which also rules out
+// (0, 0)) and [q]G == O, computed from the freshly built comb table; 0 otherwise.  One lane.
+#ifndef SSA_NO_KERNELS
+__global__ void __launch_bounds__(64)
+ssa_k_check_generator(const DevParams *__restrict__ prm, const u64 *__restrict__ gtab, unsigned *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    aff g;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        g.x.c[i] = prm->gen_x[i];
+        g.y.c[i] = prm->gen_y[i];
+    }
+    bool ok = aff_on_curve(g);
+    if (ok) {
+        sc256 q;
+#pragma unroll
+        for (int j = 0; j < 4; j++) q.w[j] = SC_Q(j);
+        ok = jac_is_identity(add_base_mul(jac_identity(), gtab, q));
+        // the table's first row must be G itself (the table was built from this blob)
+        const aff g1 = ld_aff(gtab + 12);
+        ok = ok && f6_eq(g1.x, g.x) && f6_eq(g1.y, g.y);
+    }
+    out[0] = ok ? 1u : 0u;
+}
+#endif  // SSA_NO_KERNELS
+
 // ------------------------------------------------------------------------------------------
-// scalar arithmetic mod q for signing (e = r - sk*h, src/signature.rs:124)
+// scalar arithmetic mod q: signing (e = r - sk*h, src/signature.rs:124) and the batch coefficients (src/batch.rs:92-111)
 SSA_DEV sc256 sc_dbl_mod(const sc256 &a) {  // 2a mod q, a < q < 2^255
     sc256 r;
     r.w[3] = (a.w[3] << 1) | (a.w[2] >> 63);
@@ -477,22 +624,80 @@ SSA_DEV sc256 sc_neg_mod(const sc256 &a) {  // q - a (a < q), 0 stays 0
     if (zero) r = a;
     return r;
 }
-// a*b mod q by double-and-add over the bits of b (signing only; not on the verify path)
-SSA_DEV sc256 sc_mul_mod(const sc256 &a, const sc256 &b) {
-    sc256 r;
+// 4 x 4 limbs -> 8 limbs (schoolbook; mul64x64 = four v_mad_u64_u32)
+SSA_DEV void sc_mul_4x4(const u64 (&a)[4], const u64 (&b)[4], u64 (&r)[8]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) r.w[i] = 0;
-#pragma unroll 1
-    for (int bit = 255; bit >= 0; bit--) {
-        r = sc_dbl_mod(r);
-        const u32 wi = (u32)bit >> 6;
-        u64 word = b.w[0];
-        if (wi == 1) word = b.w[1];
-        if (wi == 2) word = b.w[2];
-        if (wi == 3) word = b.w[3];
-        if ((word >> (bit & 63)) & 1ull) r = sc_add_mod(r, a);
+    for (int i = 0; i < 8; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u64 lo, hi;
+            mul64x64(a[i], b[j], lo, hi);
+            const u64 s = r[i + j] + lo;
+            const u64 c1 = s < lo;
+            const u64 s2 = s + carry;
+            const u64 c2 = s2 < s;
+            r[i + j] = s2;
+            carry = hi + c1 + c2;   // a*b + r + carry < 2^128: no overflow
+        }
+        r[i + 4] = carry;
     }
-    return r;
+}
+
+// a*b mod q for a, b < q: 256 x 256 schoolbook product and one Barrett reduction with
+// mu = floor(2^510 / q):  q3 = ((x >> 254) * mu) >> 256 is floor(x / q) or up to 2 less, so x - q3*q < 3q.
+// (was a 256-step double-and-add; hashes[i] *= scalars[i] and s_i e_i of src/batch.rs:92-111 run it twice per
+// signature in msm_k_prepare, signing (src/signature.rs:124) once.)
+SSA_DEV sc256 sc_mul_mod(const sc256 &a, const sc256 &b) {
+    const u64 MU[4] = {0xdfd9f45eab999731ULL, 0x3314f7c7edb24b7dULL, 0x8c4072a8b88f9d66ULL, 0x8542d23b3c0cc598ULL};
+    const u64 QL[4] = {SC_Q(0), SC_Q(1), SC_Q(2), SC_Q(3)};
+    u64 x[8];
+    sc_mul_4x4(a.w, b.w, x);
+    u64 q1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q1[i] = (x[3 + i] >> 62) | (x[4 + i] << 2);   // x >> 254 (x < 2^510: four limbs)
+    u64 q2[8];
+    sc_mul_4x4(q1, MU, q2);
+    const u64 q3[4] = {q2[4], q2[5], q2[6], q2[7]};
+    u64 t[8];
+    sc_mul_4x4(q3, QL, t);
+    // r = x - q3*q on five limbs (r < 3q < 2^257)
+    u64 r[5];
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const u64 d = x[i] - t[i];
+        const u64 b1 = x[i] < t[i];
+        const u64 d2 = d - borrow;
+        const u64 b2 = d < borrow;
+        r[i] = d2;
+        borrow = b1 | b2;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        sc256 lo;
+#pragma unroll
+        for (int i = 0; i < 4; i++) lo.w[i] = r[i];
+        if (r[4] != 0 || sc_geq_q(lo)) {
+            u64 bw = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u64 d = r[i] - SC_Q(i);
+                const u64 b1 = r[i] < SC_Q(i);
+                const u64 d2 = d - bw;
+                const u64 b2 = d < bw;
+                r[i] = d2;
+                bw = b1 | b2;
+            }
+            r[4] -= bw;
+        }
+    }
+    sc256 out;
+#pragma unroll
+    for (int i = 0; i < 4; i++) out.w[i] = r[i];
+    return out;
 }
 
 #ifndef SSA_NO_KERNELS
@@ -706,6 +911,26 @@ __global__ void __launch_bounds__(256) ssa_k_fpmul_bench(u64 *out, u64 seed, int
 #pragma unroll
     for (int j = 0; j < ILP; j++) acc ^= x[j] ^ y[j];
     out[t] = acc;
+}
+#endif  // SSA_NO_KERNELS
+
+// squaring chains (the shape of the Rescue S-boxes): MODE 0 = fp_mul(x, x) (four mads), 1 = fp_sqr3 (three mads)
+#ifndef SSA_NO_KERNELS
+template <int MODE>
+__global__ void __launch_bounds__(256) ssa_k_fpsqr_bench(u64 *out, u64 seed, int iters) {
+    u64 x[2];
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; j++) x[j] = seed * (t + 1) + 0x9e3779b97f4a7c15ULL * (j + 1);
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) x[j] = MODE == 0 ? fp_mul(x[j], x[j]) : fp_sqr3(x[j]);
+        }
+    }
+    out[t] = x[0] ^ x[1];
 }
 #endif  // SSA_NO_KERNELS
 

@@ -51,7 +51,8 @@ SSA_DEV void st_aff_row(u64 *__restrict__ row, const aff &p) {
 
 // ---- 1. points and scalars ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u64 *__restrict__ h_in,
+msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 *__restrict__ pk_inf,
+              const u64 *__restrict__ h_in,
               const u8 *__restrict__ coeffs, u32 coeff_bytes, size_t n, u64 *__restrict__ points,
               u64 *__restrict__ scalars, u64 *__restrict__ partials, u32 *__restrict__ malformed) {
     __shared__ u64 red[256 * 4];
@@ -66,7 +67,10 @@ msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u64
         P.y = ld_fp6(pks + 96 * i + 48, ok);
         const sc256 e = ld_sc(sigs + 81 * i + 49);
         ok = ok && !sc_geq_q(e);
-        if (ok) ok = aff_on_curve(P);
+        // an identity key is a valid PublicKey (src/public.rs:95-101); negated and fed to the MSM it adds nothing
+        // (src/batch.rs:106): the (0, 0) sentinel jac_madd skips
+        const bool p_inf = pk_inf && pk_inf[i];
+        if (ok && !p_inf) ok = aff_on_curve(P);
         aff R;
         bool r_inf = false;
         if (ok) ok = decompress_lane(sigs + 81 * i, R, r_inf) == 0;   // from_compressed(..).unwrap(), :104
@@ -78,6 +82,10 @@ msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u64
         if (r_inf) {  // identity R: the (0, 0) sentinel jac_madd skips
             R.x = f6_zero();
             R.y = f6_zero();
+        }
+        if (p_inf) {
+            P.x = f6_zero();
+            P.y = f6_zero();
         }
         sc256 s;
 #pragma unroll
@@ -266,13 +274,20 @@ msm_k_chacha20(ChaChaKey kn, u32 counter0, size_t n_blocks, u32 *__restrict__ ou
 // Verdict: x-only comparison, left.get_x() == right.get_x() (src/batch.rs:98-100, :125-129).
 __global__ void __launch_bounds__(128)
 msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict__ partials, u32 n_partials,
-             const u64 *__restrict__ gtab, const u32 *__restrict__ malformed, u32 *__restrict__ verdict) {
+             const u64 *__restrict__ gtab, const u32 *__restrict__ malformed, u32 *__restrict__ verdict,
+             u64 *__restrict__ partial_out) {
+    // partial_out != nullptr: this device holds one shard of the batch (ssa_multi_verify_batch_msm): emit the
+    // shard's left-hand point (X, Y, Z: words 0..17), its sum s_i e_i (18..21) and the malformed flag (22) instead
+    // of a verdict; device 0 adds the shards up with this same kernel (sh.c = 0: no doublings between the "windows")
     __shared__ CoopLds L;
     __shared__ u64 lin_sh[64][4];
     const u32 lane = threadIdx.x & 63u;
     const int ws = (int)(threadIdx.x >> 6);
     if (*malformed) {   // block-uniform
-        if (threadIdx.x == 0) *verdict = ST_MALFORMED;
+        if (threadIdx.x == 0) {
+            if (partial_out) partial_out[22] = 1;
+            else *verdict = ST_MALFORMED;
+        }
         return;
     }
     // slots: wave 0 accumulator 0..3 (X, Y, Z, W), addend 4..6, scratch 7..15; wave 1 accumulator 20..23,
@@ -331,12 +346,13 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
         sc256 lin;
 #pragma unroll
         for (int k = 0; k < 4; k++) lin.w[k] = lin_sh[0][k];
+        if (partial_out && lane < 4) partial_out[18 + lane] = lin.w[lane];
         coop_set(L, 20, 1ull, lane, ws);
         coop_set(L, 21, 1ull, lane, ws);
         coop_set(L, 22, 0ull, lane, ws);
         coop_set(L, 23, 0ull, lane, ws);
 #pragma unroll 1
-        for (int w = 0; w < GW_COUNT; w++) {      // BASEPOINT_TABLE.multiply_vartime
+        for (int w = 0; w < (partial_out ? 0 : GW_COUNT); w++) {      // BASEPOINT_TABLE.multiply_vartime
             const u32 d = sc_win16(lin, (u32)w);
             if (d != 0) {
                 const u64 *rowp = gtab + (((size_t)w << GW_BITS) + d) * 12;
@@ -351,6 +367,14 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
         }
     }
     __syncthreads();
+    if (partial_out) {
+        if (ws == 0 && lane < 18) partial_out[lane] = fp_canon(L.slot[(int)(lane / 6u)][lane % 6u]);
+        if (threadIdx.x == 0) {
+            partial_out[22] = 0;
+            partial_out[23] = 0;
+        }
+        return;
+    }
     if (ws == 0) {
         // X_l Z_r^2 == X_r Z_l^2; the identity's x is taken as 0
         const bool li = coop_is_zero(L, 2, lane, ws), ri = coop_is_zero(L, 22, lane, ws);
@@ -424,17 +448,35 @@ extern "C" int ssa_debug_chacha20(ssa_ctx *ctx, const uint8_t key[32], const uin
     return 0;
 }
 
+static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                   const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                   const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out);
+
 extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
-                                           const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
+                                           const uint8_t *d_pk_inf, const uint8_t *d_msgs,
+                                           const uint64_t *d_msg_off, size_t msg_stride,
                                            size_t msg_len, size_t n, const uint8_t *d_coeffs, uint32_t coeff_bytes,
                                            uint32_t *d_verdict_out) {
-    if (!ctx || !d_verdict_out) return SSA_ERR_ARG;
+    if (!d_verdict_out) return SSA_ERR_ARG;
+    return msm_run(ctx, d_sigs, d_pks, d_pk_inf, d_msgs, d_msg_off, msg_stride, msg_len, n, d_coeffs, coeff_bytes,
+                   d_verdict_out, nullptr);
+}
+
+// the kernels of one MSM-form batch on ctx->stream: a verdict (d_partial_out == nullptr) or this shard's partial sums
+static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                   const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                   const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out) {
+    if (!ctx || (!d_verdict_out && !d_partial_out)) return SSA_ERR_ARG;
     if (n && (!d_sigs || !d_pks)) return SSA_ERR_ARG;
     if (d_coeffs && (coeff_bytes == 0 || coeff_bytes > 32)) return SSA_ERR_ARG;
     if (n > (1ull << 25)) return SSA_ERR_ARG;   // 2n * 16 sort items must fit hipCUB's int item count
     if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (n == 0) {   // empty batch: Ok (src/batch.rs)
+    if (n == 0) {   // empty batch: Ok (src/batch.rs); an empty shard adds the identity and 0
+        if (d_partial_out) {
+            HIP_TRY(hipMemsetAsync(d_partial_out, 0, 24 * sizeof(u64), ctx->stream));
+            return 0;
+        }
         HIP_TRY(hipMemsetAsync(d_verdict_out, 0, sizeof(uint32_t), ctx->stream));
         return 0;
     }
@@ -476,7 +518,7 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
     // challenge scalars h_i with the kernel of the per-lane path
     if (int rc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
     int rc = timed_launch(ctx, "msm_k_prepare", [&] {
-        hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, ctx->stream, d_sigs, d_pks,
+        hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, ctx->stream, d_sigs, d_pks, d_pk_inf,
                            (const u64 *)ctx->ws_h.p, d_coeffs, coeff_bytes, n, (u64 *)ctx->msm_points.p,
                            (u64 *)ctx->msm_scalars.p, (u64 *)ctx->msm_partials.p, (u32 *)ctx->msm_flags.p);
     });
@@ -521,13 +563,76 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
         }
         hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(128), 0, ctx->stream, (const u64 *)ping, sh,
                            (const u64 *)ctx->msm_partials.p, n_blocks, (const u64 *)ctx->d_gtab,
-                           (const u32 *)ctx->msm_flags.p, d_verdict_out);
+                           (const u32 *)ctx->msm_flags.p, d_verdict_out, d_partial_out);
     });
 }
 
-extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *msgs,
-                                    const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
-                                    const uint8_t *coeffs) {
+// One shard of a batch that spans several devices: stage the host buffers, run the MSM pipeline, return the shard's
+// 24-word partial record (left-hand point, sum s_i e_i, malformed flag) in host memory.
+int ssa_internal_msm_partial(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                             const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                             const uint8_t *coeffs, uint64_t out24[24]) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::memset(out24, 0, 24 * sizeof(uint64_t));
+    if (n == 0) return 0;
+    StagedInputs s;
+    const void *p;
+    if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;
+    s.sigs = (const u8 *)p;
+    if (int rc = stage_up(ctx, ctx->st_pks, pks, n * 96, &p)) return rc;
+    s.pks = (const u8 *)p;
+    if (pk_inf) {
+        if (int rc = stage_up(ctx, ctx->st_inf, pk_inf, n, &p)) return rc;
+        s.inf = (const u8 *)p;
+    }
+    if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
+    p = nullptr;
+    if (coeffs) {
+        if (int rc = stage_up(ctx, ctx->st_coeffs, coeffs, n * 32, &p)) return rc;
+    }
+    if (ctx->st_aux2.reserve(24 * sizeof(u64))) return SSA_ERR_HIP;
+    if (int rc = msm_run(ctx, s.sigs, s.pks, s.inf, s.msgs, s.off, msg_stride, msg_len, n, (const u8 *)p, 32, nullptr,
+                         (u64 *)ctx->st_aux2.p))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out24, ctx->st_aux2.p, 24 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Device 0 adds the shards up: one Jacobian addition per shard, the scalars mod q, [lin]G from the comb table and the
+// x-only comparison (src/batch.rs:98-100,123-129) -- msm_k_finish with no doublings between its "windows".
+int ssa_internal_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (size_t j = 0; j < k; j++)
+        if (parts24[24 * j + 22]) return SSA_MALFORMED;
+    std::vector<uint64_t> pts(18 * k), lins(4 * k);
+    for (size_t j = 0; j < k; j++) {
+        std::memcpy(&pts[18 * j], parts24 + 24 * j, 18 * sizeof(uint64_t));
+        std::memcpy(&lins[4 * j], parts24 + 24 * j + 18, 4 * sizeof(uint64_t));
+    }
+    const void *d_pts, *d_lins;
+    if (int rc = stage_up(ctx, ctx->st_aux, pts.data(), pts.size() * 8, &d_pts)) return rc;
+    if (int rc = stage_up(ctx, ctx->st_aux2, lins.data(), lins.size() * 8, &d_lins)) return rc;
+    if (ctx->msm_flags.reserve(64)) return SSA_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
+    MsmShape sh;
+    sh.c = 0;
+    sh.windows = (u32)k;
+    sh.buckets = 1;
+    sh.chunks = 1;
+    uint32_t *d_verdict = (uint32_t *)((char *)ctx->ws_fail.p + 32);
+    hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(128), 0, ctx->stream, (const u64 *)d_pts, sh, (const u64 *)d_lins,
+                       (u32)k, (const u64 *)ctx->d_gtab, (const u32 *)ctx->msm_flags.p, d_verdict, (u64 *)nullptr);
+    HIP_TRY(hipGetLastError());
+    uint32_t v = SSA_MALFORMED;
+    HIP_TRY(hipMemcpyAsync(&v, d_verdict, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return (int)v;
+}
+
+extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                    const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                                    size_t n, const uint8_t *coeffs) {
     if (!ctx || (n && (!sigs || !pks))) return SSA_ERR_ARG;
     if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
     if (n == 0) return SSA_OK;
@@ -540,13 +645,17 @@ extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uin
     s.sigs = (const u8 *)p;
     if (int rc = stage_up(ctx, ctx->st_pks, pks, n * 96, &p)) return rc;
     s.pks = (const u8 *)p;
+    if (pk_inf) {
+        if (int rc = stage_up(ctx, ctx->st_inf, pk_inf, n, &p)) return rc;
+        s.inf = (const u8 *)p;
+    }
     if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
     p = nullptr;
     if (coeffs) {
         if (int rc = stage_up(ctx, ctx->st_coeffs, coeffs, n * 32, &p)) return rc;
     }
     uint32_t *d_verdict = (uint32_t *)((char *)ctx->ws_fail.p + 32);
-    if (int rc = ssa_verify_batch_msm_device(ctx, s.sigs, s.pks, s.msgs, s.off, msg_stride, msg_len, n,
+    if (int rc = ssa_verify_batch_msm_device(ctx, s.sigs, s.pks, s.inf, s.msgs, s.off, msg_stride, msg_len, n,
                                              (const u8 *)p, 32, d_verdict))
         return rc;
     uint32_t v = SSA_MALFORMED;

@@ -73,6 +73,7 @@ struct Signature;
 
 struct PublicKey {  // src/public.rs:24 -- the in-memory AffinePoint (x, y), canonical LE limbs
     std::array<uint8_t, AFFINE_PUBLIC_KEY_LENGTH> affine{};
+    bool is_identity = false;  // AffinePoint::identity() is a valid PublicKey (src/public.rs:95-101)
     Result verify_signature(Context &cx, const Signature &sig, const uint8_t *msg, size_t len) const;
 };
 
@@ -80,8 +81,11 @@ struct Signature {  // src/signature.rs:34-40, wire layout :208-214
     std::array<uint8_t, SIGNATURE_LENGTH> bytes{};
     // Signature::verify, src/signature.rs:181-205
     Result verify(Context &cx, const uint8_t *msg, size_t len, const PublicKey &pk) const {
-        return status_to_result(
-            ssa_verify(cx.get(), bytes.data(), pk.affine.data(), msg, len, SSA_FLAG_CHECK_TORSION));
+        uint8_t st = SSA_MALFORMED;
+        const uint8_t inf = pk.is_identity ? 1 : 0, dummy = 0;
+        const int rc = ssa_verify_many(cx.get(), bytes.data(), pk.affine.data(), &inf, len ? msg : &dummy, nullptr, len,
+                                       len, 1, SSA_FLAG_CHECK_TORSION, &st, nullptr);
+        return status_to_result(rc != 0 ? rc : (int)st);
     }
     std::array<uint8_t, SIGNATURE_LENGTH> to_bytes() const { return bytes; }
 };
@@ -94,16 +98,51 @@ struct KeyPair {  // src/keypair.rs:48-53
     PrivateKey private_key;
     PublicKey public_key;
 
-    static void reduce_nonzero(Rng &rng, uint8_t out[32]) {
-        // 254 random bits: below q (255 bits, top byte 0x7a) and non-zero after forcing bit 0
-        rng(out, 32);
-        out[31] &= 0x3f;
-        out[0] |= 1;
+    // Scalar::random(rng): 64 random bytes reduced mod q (statistical distance from uniform < 2^-256), never 0.
+    // (A 32-byte draw reduced mod q, or a masked 254-bit draw, is biased -- fatal for nonces: hidden-number problem.)
+    static void random_scalar(Rng &rng, uint8_t out[32]) {
+        static const uint64_t Q[4] = {0xd443623eaed4accfULL, 0x327aa72330157722ULL, 0x563fbf0f990a37b5ULL,
+                                      0x7af2599b3b3f22d0ULL};
+        for (;;) {
+            uint8_t wide[64];
+            rng(wide, sizeof wide);
+            // binary long division of the 512-bit value by q (host glue, 512 shift-subtract steps)
+            uint64_t r[4] = {0, 0, 0, 0};
+            for (int bit = 511; bit >= 0; bit--) {
+                const uint64_t top = r[3] >> 63;
+                r[3] = (r[3] << 1) | (r[2] >> 63);
+                r[2] = (r[2] << 1) | (r[1] >> 63);
+                r[1] = (r[1] << 1) | (r[0] >> 63);
+                r[0] = (r[0] << 1) | ((wide[bit >> 3] >> (bit & 7)) & 1u);
+                bool ge = top != 0;
+                if (!ge) {
+                    ge = true;
+                    for (int i = 3; i >= 0; i--) {
+                        if (r[i] != Q[i]) {
+                            ge = r[i] > Q[i];
+                            break;
+                        }
+                    }
+                }
+                if (ge) {
+                    unsigned __int128 borrow = 0;
+                    for (int i = 0; i < 4; i++) {
+                        const unsigned __int128 d = (unsigned __int128)r[i] - Q[i] - borrow;
+                        r[i] = (uint64_t)d;
+                        borrow = (d >> 64) & 1;
+                    }
+                }
+            }
+            if ((r[0] | r[1] | r[2] | r[3]) == 0) continue;   // PrivateKey::new rejects 0 (src/private.rs:49-57)
+            for (int i = 0; i < 4; i++)
+                for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(r[i] >> (8 * k));
+            return;
+        }
     }
     // KeyPair::new, src/keypair.rs:57-65
     static KeyPair create(Context &cx, Rng rng) {
         KeyPair kp;
-        reduce_nonzero(rng, kp.private_key.bytes.data());
+        random_scalar(rng, kp.private_key.bytes.data());
         uint8_t sig[SIGNATURE_LENGTH], msg = 0;
         int rc = ssa_keygen_sign_many(cx.get(), kp.private_key.bytes.data(), kp.private_key.bytes.data(), &msg,
                                       nullptr, 1, 1, 1, kp.public_key.affine.data(), sig);
@@ -113,7 +152,7 @@ struct KeyPair {  // src/keypair.rs:48-53
     // KeyPair::sign, src/signature.rs:114-129
     Signature sign(Context &cx, const uint8_t *msg, size_t len, Rng rng) const {
         uint8_t nonce[32], pk[AFFINE_PUBLIC_KEY_LENGTH];
-        reduce_nonzero(rng, nonce);
+        random_scalar(rng, nonce);
         Signature s;
         uint8_t dummy = 0;
         int rc = ssa_keygen_sign_many(cx.get(), private_key.bytes.data(), nonce, len ? msg : &dummy, nullptr, len,
@@ -126,28 +165,42 @@ struct KeyPair {  // src/keypair.rs:48-53
     }
 };
 
-// verify_batch, src/batch.rs:31-50.  `rng` is accepted for signature compatibility and unused
-// (every signature is checked exactly; DESIGN.md lists the divergence classes).
+// verify_batch, src/batch.rs:31-50.
+//   msm = false: AND of exact per-signature checks (`rng` unused; DESIGN.md lists the divergence classes)
+//   msm = true : the reference's own algorithm on the GPU (random linear combination + 2n-point MSM), the
+//                coefficients are Scalar::random(rng) per signature (src/batch.rs:75-78); rng == nullptr lets the
+//                library draw them (ChaCha20 keyed with getrandom(2))
 inline Result verify_batch(Context &cx, const std::vector<Signature> &signatures,
                            const std::vector<PublicKey> &public_keys,
-                           const std::vector<std::pair<const uint8_t *, size_t>> &messages, Rng /*rng*/ = nullptr) {
+                           const std::vector<std::pair<const uint8_t *, size_t>> &messages, Rng rng = nullptr,
+                           bool msm = false) {
     if (signatures.size() != public_keys.size())
         throw Panic("We should have the same number of signatures than public keys");  // src/batch.rs:37-40
     if (messages.size() != public_keys.size())
         throw Panic("We should have the same number of messages than public keys");    // src/batch.rs:41-44
     const size_t n = signatures.size();
     if (n == 0) return std::nullopt;
-    std::vector<uint8_t> sigs(n * SIGNATURE_LENGTH), pks(n * AFFINE_PUBLIC_KEY_LENGTH), flat;
+    std::vector<uint8_t> sigs(n * SIGNATURE_LENGTH), pks(n * AFFINE_PUBLIC_KEY_LENGTH), inf(n), flat;
     std::vector<uint64_t> off(n + 1, 0);
     for (size_t i = 0; i < n; i++) {
         std::memcpy(&sigs[i * SIGNATURE_LENGTH], signatures[i].bytes.data(), SIGNATURE_LENGTH);
         std::memcpy(&pks[i * AFFINE_PUBLIC_KEY_LENGTH], public_keys[i].affine.data(), AFFINE_PUBLIC_KEY_LENGTH);
+        inf[i] = public_keys[i].is_identity ? 1 : 0;
         flat.insert(flat.end(), messages[i].first, messages[i].first + messages[i].second);
         off[i + 1] = flat.size();
     }
     flat.push_back(0);
+    if (msm) {
+        std::vector<uint8_t> coeffs;
+        if (rng) {
+            coeffs.resize(n * SCALAR_LENGTH);
+            for (size_t i = 0; i < n; i++) KeyPair::random_scalar(rng, &coeffs[i * SCALAR_LENGTH]);
+        }
+        return status_to_result(ssa_verify_batch_msm(cx.get(), sigs.data(), pks.data(), inf.data(), flat.data(),
+                                                     off.data(), 0, 0, n, rng ? coeffs.data() : nullptr));
+    }
     return status_to_result(
-        ssa_verify_batch(cx.get(), sigs.data(), pks.data(), flat.data(), off.data(), 0, 0, n, 0));
+        ssa_verify_batch(cx.get(), sigs.data(), pks.data(), inf.data(), flat.data(), off.data(), 0, 0, n, 0));
 }
 
 }  // namespace schnorr_sig

@@ -65,6 +65,27 @@ int main() {
     std::swap(pks[1], pks[2]);
     r = verify_batch(cx, sigs, pks, msgs, rng);
     CHECK(r && *r == SignatureError::InvalidSignature);
+    // the same five through the reference's own algorithm (random linear combination + MSM)
+    std::swap(pks[1], pks[2]);
+    CHECK(!verify_batch(cx, sigs, pks, msgs, rng, true));
+    CHECK(!verify_batch(cx, sigs, pks, msgs, nullptr, true));   // library-drawn coefficients
+    std::swap(pks[1], pks[2]);
+    r = verify_batch(cx, sigs, pks, msgs, rng, true);
+    CHECK(r && *r == SignatureError::InvalidSignature);
+    // the identity is a valid PublicKey (src/public.rs:95-101): subgroup check passes, no signature verifies
+    PublicKey ident;
+    ident.is_identity = true;
+    r = sig.verify(cx, message, sizeof message, ident);
+    CHECK(r && *r == SignatureError::InvalidSignature);
+    // scalars are 64 random bytes mod q: the top byte exceeds 0x3f for about half of them
+    int high = 0;
+    for (int i = 0; i < 64; i++) {
+        uint8_t sc[32];
+        KeyPair::random_scalar(rng, sc);
+        high += sc[31] > 0x3f;
+        CHECK(sc[31] <= 0x7a);
+    }
+    CHECK(high > 8);
     bool panicked = false;
     try {
         pks.pop_back();

@@ -12,6 +12,7 @@ using namespace ssa;
 
 extern "C" {
 uint64_t ha_fp_mul(uint64_t a, uint64_t b) { return fp_canon(fp_mul(a, b)); }
+uint64_t ha_fp_sqr3(uint64_t a) { return fp_canon(fp_sqr3(a)); }
 uint64_t ha_fp_add(uint64_t a, uint64_t b) { return fp_canon(fp_add(a, b)); }
 uint64_t ha_fp_sub(uint64_t a, uint64_t b) { return fp_canon(fp_sub(a, b)); }
 uint64_t ha_fp_inv(uint64_t a) { return fp_canon(fp_inv(a)); }
@@ -100,6 +101,12 @@ void ha_sc_mul_sub(const uint64_t *r4, const uint64_t *sk4, const uint64_t *h4, 
     for (int i = 0; i < 4; i++) { r.w[i] = r4[i]; sk.w[i] = sk4[i]; h.w[i] = h4[i]; }
     sc256 e = sc_add_mod(r, sc_neg_mod(sc_mul_mod(sk, h)));
     for (int i = 0; i < 4; i++) e4[i] = e.w[i];
+}
+void ha_sc_mul(const uint64_t *a4, const uint64_t *b4, uint64_t *o4) {
+    sc256 a, b;
+    for (int i = 0; i < 4; i++) { a.w[i] = a4[i]; b.w[i] = b4[i]; }
+    const sc256 r = sc_mul_mod(a, b);
+    for (int i = 0; i < 4; i++) o4[i] = r.w[i];
 }
 void ha_sc_reduce(const uint64_t *a4, uint64_t *o4) {
     sc256 a;

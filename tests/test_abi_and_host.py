@@ -92,3 +92,35 @@ def test_shard_ranges_cover_batch():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert batch_verdict(0) == 0 and batch_verdict(3) == 2
+
+
+def test_blob_from_upstream_round_trips_the_default_blob():
+    """tools/blob_from_upstream.py: text constants -> blob.  Parsing the built-in blob and rebuilding it must give
+    the same 2816 bytes (so the day upstream's constants are typed in, the path is already exercised); the
+    plain-integer generator check accepts the default G and rejects the reference's non-subgroup fixture."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import blob_from_upstream as bfu
+    import pymodel as m
+    blob = open(os.path.join(ROOT, "schnorr-sig_amd", "params", "params_default.bin"), "rb").read()
+    spec = bfu.parse_blob(blob)
+    assert spec["rounds"] == 7 and spec["sponge"] == {"rate_offset": 0, "length_index": 11, "pad_one": False,
+                                                       "digest_offset": 0}
+    assert bfu.build_blob(spec) == blob
+    as_text = {"constants": {**spec, "mds": [[hex(v) for v in row] for row in spec["mds"]],
+                             "ark1": [[str(v) for v in row] for row in spec["ark1"]]}}
+    assert bfu.build_blob(as_text) == blob
+    circ = dict(spec)
+    circ.pop("mds")
+    circ["mds_circulant_first_row"] = spec["mds"][0]
+    assert bfu.build_blob(circ) == blob
+    assert bfu.check_generator(spec["generator"]["x"], spec["generator"]["y"]) is None
+    f = m.FIXTURE_SMALL_ORDER_PK
+    assert "outside the prime-order subgroup" in bfu.check_generator(list(f[0]), list(f[1]))
+    assert "not on" in bfu.check_generator([1, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0])
+    with pytest.raises(ValueError):
+        bfu.build_blob({**spec, "rounds": 9})
+    with pytest.raises(ValueError):
+        bad = dict(spec)
+        bad["generator"] = {"x": [2**64 - 1] + [0] * 5, "y": [0] * 6}
+        bfu.build_blob(bad)

@@ -31,6 +31,8 @@ def ha():
     for f in ("ha_fp_mul", "ha_fp_add", "ha_fp_sub"):
         getattr(lib, f).restype = C.c_uint64
         getattr(lib, f).argtypes = [C.c_uint64, C.c_uint64]
+    lib.ha_fp_sqr3.restype = C.c_uint64
+    lib.ha_fp_sqr3.argtypes = [C.c_uint64]
     lib.ha_fp_inv.restype = C.c_uint64
     lib.ha_fp_inv.argtypes = [C.c_uint64]
     lib.ha_inv_sbox.restype = C.c_uint64
@@ -50,13 +52,14 @@ def p_(a):
 
 def test_fp_ops_loose_inputs(ha):
     rnd = random.Random(1)
-    vals = EDGE + [rnd.randrange(2**64) for _ in range(200)]
+    vals = EDGE + [2**33 - 1, 2**33, 2**31, (2**32 - 1) << 32, 0x1ffffffff] + [rnd.randrange(2**64) for _ in range(200)]
     for a in vals:
         for b in EDGE + [rnd.randrange(2**64) for _ in range(8)]:
             assert ha.ha_fp_mul(a, b) == a * b % P
             assert ha.ha_fp_add(a, b) == (a + b) % P
             assert ha.ha_fp_sub(a, b) == (a - b) % P
         assert ha.ha_fp_mul_small(a, 7) == a * 7 % P
+        assert ha.ha_fp_sqr3(a) == a * a % P
         assert ha.ha_fp_mul_small(a, 0xFFFFFFFF) == a * 0xFFFFFFFF % P
         if a % P:
             assert ha.ha_fp_inv(a) == pow(a, P - 2, P)
@@ -157,6 +160,13 @@ def test_scalar_arith(ha):
         lim = lambda v: arr([(v >> (64 * i)) & (2**64 - 1) for i in range(4)])
         ha.ha_sc_mul_sub(p_(lim(r)), p_(lim(sk)), p_(lim(h)), p_(e))
         assert int.from_bytes(e.tobytes(), "little") == (r - sk * h) % Q
+    # sc_mul_mod: schoolbook + Barrett (mu = floor(2^510 / q)); edge operands stress the <= 2 corrections
+    edge = [0, 1, 2, Q - 1, Q - 2, (Q + 1) // 2, 2**254, 2**254 - 1, 2**128, 2**128 - 1, 2**64, 2**192 + 1]
+    pairs = [(a, b) for a in edge for b in edge] + [(rnd.randrange(Q), rnd.randrange(Q)) for _ in range(3000)]
+    for a, b in pairs:
+        o = np.zeros(4, np.uint64)
+        ha.ha_sc_mul(p_(lim(a)), p_(lim(b)), p_(o))
+        assert int.from_bytes(o.tobytes(), "little") == a * b % Q, (hex(a), hex(b))
     for v in (0, Q - 1, Q, Q + 1, 2 * Q, 2 * Q + 5, 2**256 - 1):
         o = np.zeros(4, np.uint64)
         ha.ha_sc_reduce(p_(arr([(v >> (64 * i)) & (2**64 - 1) for i in range(4)])), p_(o))

@@ -219,3 +219,28 @@ def test_mds_matrix_has_no_singular_minor(tmp_path):
     out = subprocess.run([exe, os.path.join(root, "schnorr-sig_amd", "params", "params_default.bin")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip() == "MDS ok 2704155", out.stdout
+
+
+def test_oracle_flag_byte_semantics_and_identity_key_in_the_batch(oracle):
+    """The oracle's restatement of verify_batch's treatment of sig.x's flag byte (src/batch.rs:104) and of an identity
+    public key (src/public.rs:95-101, src/batch.rs:106), which the round-2 GPU tests compare against."""
+    rng = np.random.default_rng(77)
+    n = 6
+    sks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); sks[:, 31] &= 0x3F; sks[:, 0] |= 1
+    nonces = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); nonces[:, 31] &= 0x3F; nonces[:, 0] |= 1
+    msgs = rng.integers(0, 256, size=(n, 20), dtype=np.uint8)
+    pks, sigs = oracle.keygen_sign_many(sks, nonces, msgs)
+    co = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); co[:, 31] &= 0x3F
+    assert (oracle.verify_many(sigs, pks, msgs, check_torsion=False, sig_flag_byte=True) == 0).all()
+    assert oracle.verify_batch_msm(sigs, pks, msgs, co) == 0
+    s2 = sigs.copy()
+    s2[1, 48] ^= 0x40          # R decodes to -R
+    s2[2, 48] |= 0x04          # undecodable
+    st = oracle.verify_many(s2, pks, msgs, check_torsion=False, sig_flag_byte=True)
+    assert list(st) == [0, 2, 3, 0, 0, 0]
+    assert list(oracle.verify_many(s2, pks, msgs, check_torsion=True)) == [0] * n      # Signature::verify ignores byte 48
+    assert oracle.verify_batch_msm(s2, pks, msgs, co) == 3
+    assert oracle.verify_batch_msm(s2[[0, 1, 3]], pks[[0, 1, 3]], msgs[[0, 1, 3]], co[:3]) == 2
+    inf = np.zeros(n, np.uint8); inf[4] = 1
+    assert oracle.verify_batch_msm(sigs, pks, msgs, co, pk_inf=inf) == 2               # key replaced by the identity
+    assert list(oracle.verify_many(sigs, pks, msgs, check_torsion=True, pk_inf=inf)) == [0, 0, 0, 0, 2, 0]

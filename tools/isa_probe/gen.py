@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generates tools/isa_probe/isa_probe.hip: a micro-benchmark of the ISSUE cost of single gfx950 VALU / SALU /
+LDS instructions (cycles per wave-instruction per SIMD), the numbers the Fp / Fp6 instruction sequences are
+designed against (DESIGN.md "instruction cost table").
+
+Each probe is a kernel whose body is one inline-asm loop of R copies of a short pattern.  Blocks of 256*w
+threads (w waves on each of the CU's 4 SIMDs; 96 KB of dynamic LDS pins one block per CU) are timed with HIP
+events; cost = elapsed / (blocks per CU * iterations * instructions per wave * w), reported in ns and relative
+to v_add_u32 at the same occupancy.
+"""
+import os
+
+R = 48          # pattern copies per loop iteration
+PROBES = []
+
+
+def probe(name, pattern, n_instr=None, setup=""):
+    """pattern: list of asm lines with {i} = copy index (used to rotate registers)."""
+    PROBES.append((name, pattern, n_instr if n_instr is not None else len(pattern), setup))
+
+
+def rot(i, base, n=8, stride=2):
+    return base + stride * (i % n)
+
+
+# independent streams: destinations rotate over 8 register (pairs) v[20..35]; sources v10..v17 fixed
+probe("v_add_u32", ["v_add_u32 v{d}, v10, v11"])
+probe("v_sub_u32", ["v_sub_u32 v{d}, v10, v11"])
+probe("v_and_b32", ["v_and_b32 v{d}, v10, v11"])
+probe("v_or_b32", ["v_or_b32 v{d}, v10, v11"])
+probe("v_xor_b32", ["v_xor_b32 v{d}, v10, v11"])
+probe("v_lshlrev_b32", ["v_lshlrev_b32 v{d}, 3, v10"])
+probe("v_lshrrev_b32", ["v_lshrrev_b32 v{d}, 3, v10"])
+probe("v_add_u32_e64", ["v_add_u32_e64 v{d}, v10, v11"])
+probe("v_max_u32", ["v_max_u32 v{d}, v10, v11"])
+probe("v_min_u32", ["v_min_u32 v{d}, v10, v11"])
+probe("v_bfe_u32", ["v_bfe_u32 v{d}, v10, 3, 7"])
+probe("v_add_lshl_u32", ["v_add_lshl_u32 v{d}, v10, v11, 3"])
+probe("v_lshl_add_u32", ["v_lshl_add_u32 v{d}, v10, 3, v11"])
+probe("v_xad_u32", ["v_xad_u32 v{d}, v10, v11, v12"])
+probe("v_sad_u32", ["v_sad_u32 v{d}, v10, v11, v12"])
+probe("v_cndmask_b32_vcc_e32", ["v_cndmask_b32 v{d}, v10, v11, vcc"], setup="vcc")
+probe("v_add3_u32", ["v_add3_u32 v{d}, v10, v11, v12"])
+probe("v_lshl_or_b32", ["v_lshl_or_b32 v{d}, v10, 3, v11"])
+probe("v_and_or_b32", ["v_and_or_b32 v{d}, v10, v11, v12"])
+probe("v_alignbit_b32", ["v_alignbit_b32 v{d}, v10, v11, 7"])
+probe("v_mov_b32", ["v_mov_b32 v{d}, v10"])
+probe("v_add_co_u32_vcc", ["v_add_co_u32 v{d}, vcc, v10, v11"])
+probe("v_add_co_u32_sgpr", ["v_add_co_u32 v{d}, s[{s}:{s1}], v10, v11"])
+probe("v_addc_co_u32_vcc", ["v_addc_co_u32 v{d}, vcc, v10, v11, vcc"])
+probe("v_addc_co_u32_sgpr", ["v_addc_co_u32 v{d}, s[{s}:{s1}], v10, v11, s[{s}:{s1}]"])
+probe("v_addc_co_u32_sgpr_fixed_in", ["v_addc_co_u32 v{d}, s[{s}:{s1}], v10, v11, s[60:61]"])
+probe("v_sub_co_u32_vcc", ["v_sub_co_u32 v{d}, vcc, v10, v11"])
+probe("v_subb_co_u32_vcc", ["v_subb_co_u32 v{d}, vcc, v10, v11, vcc"])
+probe("v_lshl_add_u64", ["v_lshl_add_u64 v[{d}:{d1}], v[10:11], 0, v[12:13]"])
+probe("v_lshlrev_b64", ["v_lshlrev_b64 v[{d}:{d1}], 5, v[10:11]"])
+probe("v_lshrrev_b64", ["v_lshrrev_b64 v[{d}:{d1}], 5, v[10:11]"])
+probe("v_cmp_lt_u32_vcc", ["v_cmp_lt_u32 vcc, v10, v11"])
+probe("v_cmp_lt_u64_vcc", ["v_cmp_lt_u64 vcc, v[10:11], v[12:13]"])
+probe("v_cmp_lt_u64_sgpr", ["v_cmp_lt_u64 s[{s}:{s1}], v[10:11], v[12:13]"])
+probe("v_cndmask_b32_vcc", ["v_cndmask_b32 v{d}, v10, v11, vcc"])
+probe("v_cndmask_b32_sgpr", ["v_cndmask_b32 v{d}, v10, v11, s[60:61]"])
+probe("v_mad_u64_u32_indep", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, v[12:13]"])
+probe("v_mad_u64_u32_sgprco", ["v_mad_u64_u32 v[{d}:{d1}], s[{s}:{s1}], v10, v11, v[12:13]"])
+probe("v_mad_u64_u32_acc", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, v[{d}:{d1}]"])
+probe("v_mad_u64_u32_zeroadd", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, 0"])
+probe("v_mul_lo_u32", ["v_mul_lo_u32 v{d}, v10, v11"])
+probe("v_mul_hi_u32", ["v_mul_hi_u32 v{d}, v10, v11"])
+probe("v_mul_u32_u24", ["v_mul_u32_u24 v{d}, v10, v11"])
+probe("v_mul_hi_u32_u24", ["v_mul_hi_u32_u24 v{d}, v10, v11"])
+probe("v_mad_u32_u24", ["v_mad_u32_u24 v{d}, v10, v11, v12"])
+probe("v_mad_u32_u16", ["v_mad_u32_u16 v{d}, v10, v11, v12"])
+probe("v_dot4_u32_u8", ["v_dot4_u32_u8 v{d}, v10, v11, v12"])
+probe("v_dot2_u32_u16", ["v_dot2_u32_u16 v{d}, v10, v11, v12"])
+probe("v_pk_mul_lo_u16", ["v_pk_mul_lo_u16 v{d}, v10, v11"])
+probe("v_pk_mad_u16", ["v_pk_mad_u16 v{d}, v10, v11, v12"])
+probe("v_fma_f32", ["v_fma_f32 v{d}, v10, v11, v12"])
+probe("v_pk_fma_f32", ["v_pk_fma_f32 v[{d}:{d1}], v[10:11], v[12:13], v[14:15]"])
+probe("v_fma_f64", ["v_fma_f64 v[{d}:{d1}], v[10:11], v[12:13], v[14:15]"])
+probe("v_add_f64", ["v_add_f64 v[{d}:{d1}], v[10:11], v[12:13]"])
+probe("v_mul_f64", ["v_mul_f64 v[{d}:{d1}], v[10:11], v[12:13]"])
+probe("v_cvt_f64_u32", ["v_cvt_f64_u32 v[{d}:{d1}], v10"])
+probe("v_cvt_u32_f64", ["v_cvt_u32_f64 v{d}, v[10:11]"])
+probe("v_accvgpr_write", ["v_accvgpr_write_b32 a{a}, v10"])
+probe("v_accvgpr_read", ["v_accvgpr_read_b32 v{d}, a{a}"])
+probe("s_xor_b64", ["s_xor_b64 s[{s}:{s1}], s[60:61], s[62:63]"])
+probe("s_and_b64", ["s_and_b64 s[{s}:{s1}], s[60:61], s[62:63]"])
+probe("ds_read_b64", ["ds_read_b64 v[{d}:{d1}], v18", ], setup="lds")
+probe("ds_read_b128", ["ds_read_b128 v[{q}:{q3}], v18"], setup="lds")
+probe("ds_write_b64", ["ds_write_b64 v18, v[10:11]"], setup="lds")
+probe("ds_write_b128", ["ds_write_b128 v18, v[10:13]"], setup="lds")
+# dependent chains
+probe("dep_v_add_u32", ["v_add_u32 v20, v20, v11"])
+probe("dep_v_mad_u64_u32", ["v_mad_u64_u32 v[20:21], vcc, v10, v11, v[20:21]"])
+probe("dep_v_lshl_add_u64", ["v_lshl_add_u64 v[20:21], v[20:21], 0, v[12:13]"])
+probe("dep_addc_chain_vcc", ["v_add_co_u32 v20, vcc, v20, v11", "v_addc_co_u32 v21, vcc, v21, v12, vcc"])
+probe("dep_addc_chain_sgpr", ["v_add_co_u32 v20, s[40:41], v20, v11", "v_addc_co_u32 v21, s[40:41], v21, v12, s[40:41]"])
+# the multiply-accumulate patterns of fp_acc: mad with carry-out + carry add into a counter
+probe("mac_pattern_vcc", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, v[{d}:{d1}]", "v_addc_co_u32 v{k}, vcc, 0, v{k}, vcc"])
+probe("mac_pattern_sgpr_gap", ["v_mad_u64_u32 v[20:21], s[40:41], v10, v11, v[20:21]",
+                               "v_mad_u64_u32 v[22:23], s[42:43], v10, v12, v[22:23]",
+                               "v_mad_u64_u32 v[24:25], s[44:45], v13, v11, v[24:25]",
+                               "v_addc_co_u32 v36, s[40:41], 0, v36, s[40:41]",
+                               "v_addc_co_u32 v37, s[42:43], 0, v37, s[42:43]",
+                               "v_addc_co_u32 v38, s[44:45], 0, v38, s[44:45]"])
+# carries counted on the scalar unit instead: bit-sliced counter planes (s_xor/s_and pairs) beside the mads
+probe("mac_pattern_salu_count", ["v_mad_u64_u32 v[20:21], s[40:41], v10, v11, v[20:21]",
+                                 "v_mad_u64_u32 v[22:23], s[42:43], v10, v12, v[22:23]",
+                                 "s_and_b64 s[46:47], s[48:49], s[40:41]",
+                                 "s_xor_b64 s[48:49], s[48:49], s[40:41]",
+                                 "s_xor_b64 s[50:51], s[50:51], s[46:47]",
+                                 "s_and_b64 s[52:53], s[54:55], s[42:43]",
+                                 "s_xor_b64 s[54:55], s[54:55], s[42:43]",
+                                 "s_xor_b64 s[56:57], s[56:57], s[52:53]"], n_instr=2)
+probe("mads_plus_4salu", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, v[12:13]", "s_xor_b64 s[40:41], s[60:61], s[62:63]",
+                          "s_and_b64 s[42:43], s[60:61], s[62:63]", "s_xor_b64 s[44:45], s[60:61], s[62:63]",
+                          "s_and_b64 s[46:47], s[60:61], s[62:63]"], n_instr=1)
+probe("add_plus_1salu", ["v_add_u32 v{d}, v10, v11", "s_xor_b64 s[40:41], s[60:61], s[62:63]"], n_instr=1)
+# mixes: 1 mad + k plain ops (is the multiplier pipelined beside the adder?)
+probe("mad_plus_1add", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, v[12:13]", "v_add_u32 v36, v10, v11"])
+probe("mad_plus_2add", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, v[12:13]", "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11"])
+probe("mad_plus_3add", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, v[12:13]", "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11", "v_add_u32 v38, v10, v12"])
+probe("mad_plus_3and", ["v_mad_u64_u32 v[{d}:{d1}], vcc, v10, v11, v[12:13]", "v_and_b32 v36, v10, v11", "v_and_b32 v37, v10, v11", "v_and_b32 v38, v10, v12"])
+probe("addc_plus_3add", ["v_addc_co_u32 v{d}, s[{s}:{s1}], v10, v11, s[60:61]", "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11", "v_add_u32 v38, v10, v12"])
+probe("fma64_plus_3add", ["v_fma_f64 v[{d}:{d1}], v[10:11], v[12:13], v[14:15]", "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11", "v_add_u32 v38, v10, v12"])
+probe("mad4_then_add4", ["v_mad_u64_u32 v[20:21], vcc, v10, v11, v[12:13]", "v_mad_u64_u32 v[22:23], vcc, v10, v11, v[12:13]",
+                         "v_mad_u64_u32 v[24:25], vcc, v10, v11, v[12:13]", "v_mad_u64_u32 v[26:27], vcc, v10, v11, v[12:13]",
+                         "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11", "v_add_u32 v38, v10, v12", "v_add_u32 v39, v10, v12"])
+probe("mad_addc_pairs", ["v_mad_u64_u32 v[20:21], s[40:41], v10, v11, v[20:21]", "v_mad_u64_u32 v[22:23], s[42:43], v10, v12, v[22:23]",
+                         "v_addc_co_u32 v36, s[40:41], 0, v36, s[40:41]", "v_addc_co_u32 v37, s[42:43], 0, v37, s[42:43]"])
+probe("ds_read_b128_plus_4add", ["ds_read_b128 v[{q}:{q3}], v18", "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11", "v_add_u32 v38, v10, v12", "v_add_u32 v39, v10, v12"], n_instr=5, setup="lds")
+
+
+def body(pattern):
+    lines = []
+    for i in range(R):
+        d = 20 + 2 * (i % 8)
+        q = 20 + 4 * (i % 4)
+        s = 40 + 2 * (i % 8)
+        fm = dict(i=i, d=d, d1=d + 1, q=q, q3=q + 3, s=s, s1=s + 1, k=36 + (i % 4), a=i % 16)
+        for ln in pattern:
+            lines.append(ln.format(**fm))
+    return lines
+
+
+def main():
+    out = ["// generated by tools/isa_probe/gen.py -- do not edit", "#include <hip/hip_runtime.h>", "#include <cstdio>",
+           "#include <cstring>", "#include <vector>", ""]
+    clob = ", ".join('"v%d"' % r for r in range(10, 40)) + ", " + ", ".join('"s%d"' % r for r in range(36, 64)) + \
+        ', "vcc", "scc", "memory"'
+    for name, pattern, n_instr, setup in PROBES:
+        lines = body(pattern)
+        out.append("__global__ void __launch_bounds__(1024) k_%s(int iters, unsigned *out) {" % name)
+        out.append("    extern __shared__ unsigned lds[];")
+        out.append("    unsigned x = threadIdx.x, y;")
+        out.append("    asm volatile(")
+        pre = ["v_mov_b32 v%d, %%1" % r for r in range(10, 40)]
+        pre += ["v_lshlrev_b32 v18, 4, %1", "s_mov_b64 vcc, exec", "s_mov_b64 s[60:61], exec", "s_mov_b64 s[62:63], 0", "s_mov_b32 s36, %2"]
+        pre += ["s_mov_b64 s[%d:%d], 0" % (s, s + 1) for s in range(40, 60, 2)]
+        for ln in pre:
+            out.append('        "%s\\n\\t"' % ln)
+        out.append('        "L_%s_%%=:\\n\\t"' % name)
+        for ln in lines:
+            out.append('        "%s\\n\\t"' % ln)
+        if setup == "lds":
+            out.append('        "s_waitcnt lgkmcnt(0)\\n\\t"')
+        out.append('        "s_sub_u32 s36, s36, 1\\n\\t"')
+        out.append('        "s_cmp_lg_u32 s36, 0\\n\\t"')
+        out.append('        "s_cbranch_scc1 L_%s_%%=\\n\\t"' % name)
+        out.append('        "v_xor_b32 %0, v20, v21"')
+        out.append('        : "=v"(y) : "v"(x), "s"(iters) : %s);' % clob)
+        out.append("    if (y == 0x12345u) out[threadIdx.x] = y + lds[0];")
+        out.append("}")
+        out.append("")
+    out.append("struct Probe { const char *name; void (*fn)(int, unsigned *); int per_iter; };")
+    out.append("static const Probe probes[] = {")
+    for name, pattern, n_instr, setup in PROBES:
+        out.append('    {"%s", k_%s, %d},' % (name, name, R * n_instr))
+    out.append("};")
+    out.append(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "main.inc")).read())
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "isa_probe.hip"), "w") as fh:
+        fh.write("\n".join(out) + "\n")
+    print("%d probes" % len(PROBES))
+
+
+if __name__ == "__main__":
+    main()
