@@ -27,7 +27,11 @@ SSA_DEV jac jac_identity() {
 }
 SSA_DEV bool jac_is_identity(const jac &p) { return f6_is_zero(p.Z); }
 
-// dbl-2007-bl with a = 1: 1M + 8S
+// dbl-2007-bl with a = 1: 1M + 8S.  The additions of the formula ride in the accumulators of the products they
+// follow (f6_sqr_sub2 & co.); three modular additions are left (t, yz, D).  With S' = S / 2 = 2 X Y^2:
+//   S' = (X + YY)^2 - XX - YYYY      M = ZZ^2 + 3 XX      X3 = M^2 - 4 S'
+//   Y3 = M (2 S' - X3) - 8 YYYY      Z3 = (Y + Z)^2 - YY - ZZ
+#ifdef SSA_DBL_PLAIN
 SSA_DEV jac jac_dbl(const jac &p) {
     fp6 XX = f6_sqr(p.X);
     fp6 YY = f6_sqr(p.Y);
@@ -44,6 +48,25 @@ SSA_DEV jac jac_dbl(const jac &p) {
     r.Z = f6_sub(f6_sub(f6_sqr(yz), YY), ZZ);
     return r;
 }
+#else
+SSA_DEV jac jac_dbl(const jac &p) {
+    const fp6 XX = f6_sqr(p.X);
+    const fp6 YY = f6_sqr(p.Y);
+    const fp6 YYYY = f6_sqr(YY);
+    const fp6 ZZ = f6_sqr(p.Z);
+    const fp6 Sh = f6_sqr_sub2(f6_add(p.X, YY), XX, YYYY);
+    const fp6 M = f6_sqr_add3x(ZZ, XX);
+    jac r;
+    r.X = f6_sqr_sub4x(M, Sh);
+    r.Y = f6_mul_sub8x(M, f6_sub(f6_dbl(Sh), r.X), YYYY);
+    r.Z = f6_sqr_sub2(f6_add(p.Y, p.Z), YY, ZZ);
+    return r;
+}
+#endif
+
+// the doubling as a shared out-of-line body for the rare P == Q branches of the additions (keeps the five inlined
+// product blocks of jac_dbl out of the ladder's addition code)
+SSA_FN void jac_dbl_cold(jac *__restrict__ r, const jac *__restrict__ p) { *r = jac_dbl(*p); }
 
 // mixed addition p + (x2, y2): 7M + 4S on the generic path.  The affine pair (0, 0) -- not a
 // curve point since B != 0 -- is the table's encoding of the identity.
@@ -57,7 +80,11 @@ SSA_DEV jac jac_madd(const jac &p, const aff &q) {
     const bool q_inf = f6_is_zero(q.x) && f6_is_zero(q.y);
     const bool h0 = f6_is_zero(H);
     const bool r0 = f6_is_zero(R);
-    if (!p_inf && !q_inf && h0 && r0) return jac_dbl(p);  // p == q (rare, divergent)
+    if (!p_inf && !q_inf && h0 && r0) {  // p == q (rare, divergent)
+        jac d;
+        jac_dbl_cold(&d, &p);
+        return d;
+    }
     fp6 HH = f6_sqr(H);
     fp6 HHH = f6_mul(H, HH);
     fp6 V = f6_mul(p.X, HH);
@@ -86,7 +113,11 @@ SSA_DEV jac jac_add(const jac &p, const jac &q) {
     fp6 R = f6_sub(S2, S1);
     const bool p_inf = f6_is_zero(p.Z);
     const bool q_inf = f6_is_zero(q.Z);
-    if (!p_inf && !q_inf && f6_is_zero(H) && f6_is_zero(R)) return jac_dbl(p);
+    if (!p_inf && !q_inf && f6_is_zero(H) && f6_is_zero(R)) {
+        jac d;
+        jac_dbl_cold(&d, &p);
+        return d;
+    }
     fp6 HH = f6_sqr(H);
     fp6 HHH = f6_mul(H, HH);
     fp6 V = f6_mul(U1, HH);

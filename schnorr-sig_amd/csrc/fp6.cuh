@@ -183,6 +183,101 @@ SSA_FN fp6 f6_sqr_flat(u64 a0, u64 a1, u64 a2_, u64 a3, u64 a4, u64 a5) {
 }
 SSA_DEV fp6 f6_sqr(const fp6 &a) { return f6_sqr_flat(a.c[0], a.c[1], a.c[2], a.c[3], a.c[4], a.c[5]); }
 
+// ---- products fused with the additions that follow them in the point formulas -------------------------------
+// r = a^2 (or a*b) + sum of small multiples of other elements, the linear terms added to the accumulator columns
+// before the single reduction (fp6_asm.inc, "fused linear terms": 4-6 instructions per coefficient and term instead
+// of the ~10 of a modular addition).  Inlined at their call sites (one each in jac_dbl / jac_madd): no call, no
+// argument moves.  Host build and -DSSA_NO_F6_ASM: the same value from the plain operations.
+SSA_DEV void f6_sqr_prescale(const fp6 &a, u64 (&a2)[6], u64 (&a7)[6], u64 (&a14)[6]) {
+    a2[0] = 0ull;
+#pragma unroll
+    for (int j = 0; j < 3; j++) a7[j] = a14[j] = 0ull;
+#pragma unroll
+    for (int j = 1; j < 6; j++) a2[j] = fp_dbl(a.c[j]);
+#pragma unroll
+    for (int j = 3; j < 6; j++) {
+        a7[j] = fp_mul_small(a.c[j], 7u);
+        a14[j] = fp_dbl(a7[j]);
+    }
+}
+SSA_DEV void f6_mul_prescale(const fp6 &b, u64 (&b7)[6]) {
+    b7[0] = 0ull;
+#pragma unroll
+    for (int j = 1; j < 6; j++) b7[j] = fp_mul_small(b.c[j], 7u);
+}
+// a^2 - x - y
+SSA_DEV fp6 f6_sqr_sub2(const fp6 &a, const fp6 &x, const fp6 &y) {
+#ifdef SSA_F6_ASM
+    u64 a2[6], a7[6], a14[6];
+    f6_sqr_prescale(a, a2, a7, a14);
+    fp6 r;
+    f6_sqr_sub2_core_asm(a.c, a2, a7, a14, x.c, y.c, r.c);
+    return r;
+#else
+    return f6_sub(f6_sub(f6_sqr(a), x), y);
+#endif
+}
+// a^2 - x - 2y
+SSA_DEV fp6 f6_sqr_subx_sub2y(const fp6 &a, const fp6 &x, const fp6 &y) {
+#ifdef SSA_F6_ASM
+    u64 a2[6], a7[6], a14[6];
+    f6_sqr_prescale(a, a2, a7, a14);
+    fp6 r;
+    f6_sqr_subx_sub2y_core_asm(a.c, a2, a7, a14, x.c, y.c, r.c);
+    return r;
+#else
+    return f6_sub(f6_sub(f6_sqr(a), x), f6_dbl(y));
+#endif
+}
+// a^2 + 3x
+SSA_DEV fp6 f6_sqr_add3x(const fp6 &a, const fp6 &x) {
+#ifdef SSA_F6_ASM
+    u64 a2[6], a7[6], a14[6];
+    f6_sqr_prescale(a, a2, a7, a14);
+    fp6 r;
+    f6_sqr_add3x_core_asm(a.c, a2, a7, a14, x.c, r.c);
+    return r;
+#else
+    return f6_add(f6_sqr(a), f6_add(f6_dbl(x), x));
+#endif
+}
+// a^2 - 4x
+SSA_DEV fp6 f6_sqr_sub4x(const fp6 &a, const fp6 &x) {
+#ifdef SSA_F6_ASM
+    u64 a2[6], a7[6], a14[6];
+    f6_sqr_prescale(a, a2, a7, a14);
+    fp6 r;
+    f6_sqr_sub4x_core_asm(a.c, a2, a7, a14, x.c, r.c);
+    return r;
+#else
+    return f6_sub(f6_sqr(a), f6_dbl(f6_dbl(x)));
+#endif
+}
+// a*b - 8x
+SSA_DEV fp6 f6_mul_sub8x(const fp6 &a, const fp6 &b, const fp6 &x) {
+#ifdef SSA_F6_ASM
+    u64 b7[6];
+    f6_mul_prescale(b, b7);
+    fp6 r;
+    f6_mul_sub8x_core_asm(a.c, b.c, b7, x.c, r.c);
+    return r;
+#else
+    return f6_sub(f6_mul(a, b), f6_dbl(f6_dbl(f6_dbl(x))));
+#endif
+}
+// a*b - x
+SSA_DEV fp6 f6_mul_subx(const fp6 &a, const fp6 &b, const fp6 &x) {
+#ifdef SSA_F6_ASM
+    u64 b7[6];
+    f6_mul_prescale(b, b7);
+    fp6 r;
+    f6_mul_subx_core_asm(a.c, b.c, b7, x.c, r.c);
+    return r;
+#else
+    return f6_sub(f6_mul(a, b), x);
+#endif
+}
+
 // Frobenius x -> x^(p^k): c_i *= gamma^(i k), gamma = 7^((p-1)/6) = 2^64-2^33+2 (mod p).
 // Powers of gamma: 1, g, -2^32, -1, 2^32-1 (= 2^64), 2^32.
 SSA_DEV u64 fp_mul_gpow(u64 x, int e) {

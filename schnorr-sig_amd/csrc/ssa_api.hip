@@ -829,8 +829,8 @@ extern "C" int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, con
 // ------------------------------------------------------------------ probes
 extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                                size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {
-    if (!ctx || !a || !out || n == 0 || op < 0 || op > 7) return SSA_ERR_ARG;
-    if ((op == 0 || op == 3 || op == 4 || op == 5 || op == 7) && !b) return SSA_ERR_ARG;
+    if (!ctx || !a || !out || n == 0 || op < 0 || op > 13) return SSA_ERR_ARG;
+    if ((op == 0 || op == 3 || op == 4 || op == 5 || op >= 7) && !b) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const void *da, *db = nullptr;
     if (int rc = stage_up(ctx, ctx->st_aux, a, n * a_stride * 8, &da)) return rc;

@@ -834,6 +834,26 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
         for (int k = 0; k < 6; k++) po[k] = r.c[k];
         return;
     }
+    if (op >= 8 && op <= 13) {   // fused product + linear terms: a = (a, b), b = (x, y)
+        fp6 u, v, x, y, r;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            u.c[k] = pa[k];
+            v.c[k] = pa[6 + k];
+            x.c[k] = pb[k];
+            y.c[k] = pb[6 + k];
+        }
+        if (op == 8) r = f6_sqr_sub2(u, x, y);
+        else if (op == 9) r = f6_sqr_add3x(u, x);
+        else if (op == 10) r = f6_sqr_sub4x(u, x);
+        else if (op == 11) r = f6_mul_sub8x(u, v, x);
+        else if (op == 12) r = f6_mul_subx(u, v, x);
+        else r = f6_sqr_subx_sub2y(u, x, y);
+        r = f6_canon(r);
+#pragma unroll
+        for (int k = 0; k < 6; k++) po[k] = r.c[k];
+        return;
+    }
     if (op == 3) {  // affine + affine (a[12] = inf flag, b[12] = inf flag) -> 12 felts + inf
         aff p, q;
 #pragma unroll

@@ -425,3 +425,42 @@ def test_upstream_vectors_if_present(oracle):
             assert eng.verify_one(sig, pk96, msg, check_torsion=True, pk_is_identity=is_inf) == want
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------- fused product + linear-term blocks
+def test_fused_product_blocks(engine):
+    """The Fp6 products whose following additions ride in the accumulator (fp6_asm.inc, fused linear terms): every
+    block against plain integers, loose (non-canonical) operands and edge values included."""
+    rng = np.random.default_rng(1234)
+    edge = [0, 1, P - 1, P, P + 1, 2**32 - 1, 2**32, 2**64 - 1, 2**64 - 2**32, 2**63]
+    n = 3000
+    a = rng.integers(0, 2**64, size=(n, 12), dtype=np.uint64)
+    b = rng.integers(0, 2**64, size=(n, 12), dtype=np.uint64)
+    for r in range(len(edge) * len(edge)):
+        a[r] = np.uint64(edge[r % len(edge)])
+        b[r] = np.uint64(edge[r // len(edge)])
+    a[200] = 0
+    b[200] = np.uint64(2**64 - 1)
+    a[201] = np.uint64(2**64 - 1)
+    b[201] = 0
+
+    def mulmod(u, v):
+        t = [0] * 12
+        for i, x in enumerate(u):
+            for j, y in enumerate(v):
+                t[i + j] += x * y
+        return [(t[k] + 7 * t[k + 6]) % P for k in range(6)]
+
+    ops = {8: lambda u, v, x, y: [(m - p_ - q) % P for m, p_, q in zip(mulmod(u, u), x, y)],
+           9: lambda u, v, x, y: [(m + 3 * p_) % P for m, p_ in zip(mulmod(u, u), x)],
+           10: lambda u, v, x, y: [(m - 4 * p_) % P for m, p_ in zip(mulmod(u, u), x)],
+           11: lambda u, v, x, y: [(m - 8 * p_) % P for m, p_ in zip(mulmod(u, v), x)],
+           12: lambda u, v, x, y: [(m - p_) % P for m, p_ in zip(mulmod(u, v), x)],
+           13: lambda u, v, x, y: [(m - p_ - 2 * q) % P for m, p_, q in zip(mulmod(u, u), x, y)]}
+    check = list(range(260)) + list(range(260, n, 13))
+    for op, model in ops.items():
+        got = engine.debug_arith(op, a, b, 6)
+        for i in check:
+            u, v = [int(t) for t in a[i, :6]], [int(t) for t in a[i, 6:]]
+            x, y = [int(t) for t in b[i, :6]], [int(t) for t in b[i, 6:]]
+            assert [int(t) for t in got[i]] == model(u, v, x, y), (op, i)

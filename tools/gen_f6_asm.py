@@ -62,16 +62,19 @@ class Acc:
 S0, S1 = "s[0:1]", "s[2:3]"
 
 
-def init2(acc, x, y, z, w):
-    """acc = x*y + z*w; operands are names of u64 inputs (halves %[<name>l] / %[<name>h])."""
+def init2(acc, x, y, z, w, bias=None):
+    """acc = x*y + z*w (+ bias); operands are names of u64 inputs (halves %[<name>l] / %[<name>h]).
+    bias = (c0 addend, c2 addend): constants below 2^33 - 1 ride for free in the zero addends of the opening
+    multiplies ((2^32-1)^2 + 2^33 - 2 < 2^64, so those still cannot carry)."""
+    b0, b2 = bias if bias else ("0", "0")
     xl, xh, yl, yh = "%%[%sl]" % x, "%%[%sh]" % x, "%%[%sl]" % y, "%%[%sh]" % y
     zl, zh, wl, wh = "%%[%sl]" % z, "%%[%sh]" % z, "%%[%sl]" % w, "%%[%sh]" % w
     c0, c1, c2 = acc.pair(0), acc.pair(1), acc.pair(2)
     k0, k1, k2 = acc.kk(0), acc.kk(1), acc.kk(2)
     return [
-        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (c0, S0, xl, yl),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c0, S0, xl, yl, b0),
         "v_mad_u64_u32 %s, %s, %s, %s, 0" % (c1, S0, xl, yh),
-        "v_mad_u64_u32 %s, %s, %s, %s, 0" % (c2, S0, xh, yh),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c2, S0, xh, yh, b2),
         "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (c1, xh, yl, c1),
         "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c0, S0, zl, wl, c0),
         "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c1, S1, zl, wh, c1),
@@ -99,6 +102,73 @@ def mac(acc, x, y):
         "v_addc_co_u32 %s, %s, 0, %s, %s" % (k2, S1, k2, S1),
         "v_addc_co_u32 %s, vcc, 0, %s, vcc" % (k1, k1),
     ]
+
+
+# ---- fused linear terms ---------------------------------------------------------------------------------------
+# r_k = (products)_k + sum_j sign_j * c_j * x_j[k] with small constants c_j, added to the accumulator columns BEFORE the
+# reduction: one multiply per 32-bit half (c0 += c * x_lo, c1 += c * x_hi) and the two carry adds, instead of a
+# separate modular addition (about ten instructions with its two wrap-around fix-ups).
+# A negative term uses the complement: -x = ~x + 1 - 2^64 = ~x - (2^32 - 2) (mod p), so c * ~x is accumulated (two
+# v_not more) and the constants -(2^32 - 2) * C, C = sum of the negative c_j, are paid once per coefficient -- for free:
+#   (C + 1) + (2^32 - C) * 2^64 = C + 1 + 2^96 - C * 2^64 = 2C - C * 2^32 = -C (2^32 - 2)   (2^96 = -1, 2^64 = 2^32 - 1)
+# i.e. the opening multiplies of columns c0 and c2 start from C + 1 and 2^32 - C instead of 0 (init2's bias).
+BIAS_SGPR = "s[12:13]"
+XT = POOL[33:37]          # complements of up to two negative operands
+
+
+def extras_bias(extras):
+    c_neg = sum(c for sign, c, _ in extras if sign < 0)
+    if c_neg == 0:
+        return None, []
+    assert c_neg + 1 <= 64
+    return (str(c_neg + 1), BIAS_SGPR), ["s_mov_b32 s12, %d" % (-c_neg), "s_mov_b32 s13, 0"]
+
+
+def extra_terms(acc, k, extras):
+    """instruction list for coefficient k; every carry (s[0:1], s[2:3], vcc) has two instructions between its
+    producer and its consumer (s_nop where nothing else is left to place)"""
+    if not extras:
+        return []
+    c0, c1 = acc.pair(0), acc.pair(1)
+    k0, k1 = acc.kk(0), acc.kk(1)
+    pre, mads, adds = [], [], []
+    t = 0
+    carries0 = [S0, S1]
+    for n, (sign, c, name) in enumerate(extras):
+        lo, hi = "%%[%s%dl]" % (name, k), "%%[%s%dh]" % (name, k)
+        if sign < 0:
+            pre += ["v_not_b32 v%d, %s" % (XT[t], lo), "v_not_b32 v%d, %s" % (XT[t + 1], hi)]
+            lo, hi = "v%d" % XT[t], "v%d" % XT[t + 1]
+            t += 2
+        cs = carries0[n % 2]
+        mads.append(("v_mad_u64_u32 %s, %s, %s, %d, %s" % (c0, cs, lo, c, c0), "v_addc_co_u32 %s, %s, 0, %s, %s" % (k0, cs, k0, cs)))
+        mads.append(("v_mad_u64_u32 %s, vcc, %s, %d, %s" % (c1, hi, c, c1), "v_addc_co_u32 %s, vcc, 0, %s, vcc" % (k1, k1)))
+    # schedule: producers in order, each consumer as early as two instructions after its producer; vcc has one
+    # producer in flight at a time
+    out = list(pre)
+    pending = []   # (consumer, index of producer in out)
+    for prod, cons in mads:
+        is_vcc = ", vcc," in prod
+        if is_vcc:   # the previous vcc carry must be consumed first
+            for j, (pc, pi) in enumerate(pending):
+                if ", vcc" in pc:
+                    while len(out) - pi - 1 < 2:
+                        out.append("s_nop 0")
+                    out.append(pc)
+                    pending.pop(j)
+                    break
+        # flush consumers that are ready (oldest first)
+        for pc, pi in list(pending):
+            if len(out) - pi - 1 >= 2:
+                out.append(pc)
+                pending.remove((pc, pi))
+        out.append(prod)
+        pending.append((cons, len(out) - 1))
+    for pc, pi in pending:
+        while len(out) - pi - 1 < 2:
+            out.append("s_nop 0")
+        out.append(pc)
+    return out
 
 
 REDUCE_STEPS = [
@@ -164,16 +234,20 @@ def sqr_terms():
     return out
 
 
-def emit(name, terms, inputs, doc):
+def emit(name, terms, inputs, doc, extras=()):
+    """extras: fused linear terms (sign, small constant, operand prefix); their operand arrays are appended to inputs"""
     accs = [Acc(j) for j in range(6)]
     lines = []
+    bias, bias_setup = extras_bias(extras)
+    lines += bias_setup
     for g in range(2):
         for k in range(3 * g, 3 * g + 3):
             t = terms[k]
             assert len(t) >= 2
-            lines += init2(accs[k], t[0][0], t[0][1], t[1][0], t[1][1])
+            lines += init2(accs[k], t[0][0], t[0][1], t[1][0], t[1][1], bias)
             for x, y in t[2:]:
                 lines += mac(accs[k], x, y)
+            lines += extra_terms(accs[k], k, extras)
         if g == 0:   # inputs are still needed: park the results in fixed registers
             outs = [("v%d" % RES[2 * j], "v%d" % RES[2 * j + 1]) for j in range(3)]
         else:
@@ -205,7 +279,9 @@ def emit(name, terms, inputs, doc):
                 ins.append('[%sl] "v"(lo32(%s[%d]))' % (nm, arr, j))
                 ins.append('[%sh] "v"(hi32(%s[%d]))' % (nm, arr, j))
     out.append("        : " + ",\n          ".join(ins))
-    clob = ['"v%d"' % r for r in POOL[:N_FIXED]] + ['"s%d"' % i for i in range(12)] + ['"vcc"']
+    n_fixed = N_FIXED + (4 if any(sg < 0 for sg, _, _ in extras) else 0)
+    n_sgpr = 14 if bias else 12
+    clob = ['"v%d"' % r for r in POOL[:n_fixed]] + ['"s%d"' % i for i in range(n_sgpr)] + ['"vcc"']
     out.append("        : " + ", ".join(clob) + ");")
     for j in range(6):
         out.append("    r[%d] = mk64(r%dl, r%dh);" % (j, j, j))
@@ -222,10 +298,25 @@ def main():
     s, nl, nm = emit("f6_sqr_core_asm", sqr_terms(), [("a", "a"), ("a2", "d"), ("a7", "s"), ("a14", "t")],
                      "r = a^2; a2[j] = 2 a[j] (j = 1..5), a7[j] = 7 a[j], a14[j] = 14 a[j] (j = 3..5)")
     print("sqr: %d instructions, %d mads" % (nl, nm))
+    sqr_in = [("a", "a"), ("a2", "d"), ("a7", "s"), ("a14", "t")]
+    mul_in = [("a", "a"), ("b", "b"), ("b7", "s")]
+    fused = []
+    for nm, terms, ins, ex, doc in (
+            ("f6_sqr_sub2_core_asm", sqr_terms(), sqr_in + [("x", "x"), ("y", "y")], [(-1, 1, "x"), (-1, 1, "y")],
+             "r = a^2 - x - y (prescaled operands as f6_sqr_core_asm)"),
+            ("f6_sqr_add3x_core_asm", sqr_terms(), sqr_in + [("x", "x")], [(+1, 3, "x")], "r = a^2 + 3 x"),
+            ("f6_sqr_sub4x_core_asm", sqr_terms(), sqr_in + [("x", "x")], [(-1, 4, "x")], "r = a^2 - 4 x"),
+            ("f6_mul_sub8x_core_asm", mul_terms(), mul_in + [("x", "x")], [(-1, 8, "x")], "r = a * b - 8 x"),
+            ("f6_mul_subx_core_asm", mul_terms(), mul_in + [("x", "x")], [(-1, 1, "x")], "r = a * b - x"),
+            ("f6_sqr_subx_sub2y_core_asm", sqr_terms(), sqr_in + [("x", "x"), ("y", "y")], [(-1, 1, "x"), (-1, 2, "y")],
+             "r = a^2 - x - 2 y")):
+        blk, nl, nmad = emit(nm, terms, ins, doc, ex)
+        print("%s: %d instructions, %d mads" % (nm, nl, nmad))
+        fused += [""] + blk
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc",
                         "fp6_asm.inc")
     with open(path, "w") as fh:
-        fh.write("\n".join(hdr + m + [""] + s) + "\n")
+        fh.write("\n".join(hdr + m + [""] + s + fused) + "\n")
     print("wrote", path)
 
 
