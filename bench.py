@@ -54,7 +54,7 @@ BYTES_PER_VERIFY = 81 + 96 + 80 + 1             # algorithmic HBM bytes (SURVEY.
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9            # MI355X_MICROARCH.md: 256 CU x 4 SIMD-32 x 2.4 GHz
 PEAK_FPMUL = VALU_LANE_OPS / 16                 # 4 quarter-rate v_mad_u64_u32 per product, nothing else
 PEAK_HBM_GBPS = 8000.0
-LIB = os.path.join(ROOT, "schnorr-sig_amd", "csrc", "libschnorr_sig_amd.so")
+LIB = os.environ.get("SSA_LIB") or os.path.join(ROOT, "schnorr-sig_amd", "csrc", "libschnorr_sig_amd.so")
 
 
 def parse_args(argv=None):

@@ -250,8 +250,8 @@ int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, const uint8_t 
  *     4 = scalar mul [k]P (k in a[0..4], P in b), 5 = Fp mul (a[0]*b[0]), 6 = Fp inv,
  *     7 = the cooperative (one wave per point) operations: a = (x, y, inf, mode), b = (x, y, inf);
  *         mode 0 mixed addition, 1 general addition of two scaled Jacobian points, 2 doubling of a
- *     8..13 = products fused with linear terms, a = (u, v) 12 felts, b = (x, y) 12 felts -> 6 felts:
- *         8 u^2 - x - y, 9 u^2 + 3x, 10 u^2 - 4x, 11 u*v - 8x, 12 u*v - x, 13 u^2 - x - 2y */
+ *     8..14 = products fused with linear terms, a = (u, v) 12 felts, b = (x, y) 12 felts -> 6 felts:
+ *         8 u^2 - x - y, 9 u^2 + 3x, 10 u^2 - 4x, 11 u*v - 8x, 12 u*v - x, 13 u^2 - x - 2y, 14 u*v + x*y */
 int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                     size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride);
 /* n_blocks 64-byte blocks of the ChaCha20 keystream the MSM coefficients come from (RFC 8439 known answers) */

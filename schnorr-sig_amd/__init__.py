@@ -20,7 +20,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libschnorr_sig_amd.so")
+# SSA_LIB: an alternative build of the same library (kernel experiments, tools/build_variants.sh); default: in-tree
+LIB_PATH = os.environ.get("SSA_LIB") or os.path.join(_HERE, "csrc", "libschnorr_sig_amd.so")
 
 # src/constants.rs:12-30
 SCALAR_LENGTH = 32

@@ -50,10 +50,17 @@ SSA_DEV jac jac_dbl(const jac &p) {
 }
 #else
 SSA_DEV jac jac_dbl(const jac &p) {
+#ifdef SSA_DBL_INLINE
+    const fp6 XX = f6_sqr_inl(p.X);
+    const fp6 YY = f6_sqr_inl(p.Y);
+    const fp6 YYYY = f6_sqr_inl(YY);
+    const fp6 ZZ = f6_sqr_inl(p.Z);
+#else
     const fp6 XX = f6_sqr(p.X);
     const fp6 YY = f6_sqr(p.Y);
     const fp6 YYYY = f6_sqr(YY);
     const fp6 ZZ = f6_sqr(p.Z);
+#endif
     const fp6 Sh = f6_sqr_sub2(f6_add(p.X, YY), XX, YYYY);
     const fp6 M = f6_sqr_add3x(ZZ, XX);
     jac r;
@@ -69,13 +76,22 @@ SSA_DEV jac jac_dbl(const jac &p) {
 SSA_FN void jac_dbl_cold(jac *__restrict__ r, const jac *__restrict__ p) { *r = jac_dbl(*p); }
 
 // mixed addition p + (x2, y2): 7M + 4S on the generic path.  The affine pair (0, 0) -- not a
-// curve point since B != 0 -- is the table's encoding of the identity.
+// curve point since B != 0 -- is the table's encoding of the identity.  As in jac_dbl the subtractions ride in the
+// accumulators of the products they follow, and R (V - X3) - Y1 HHH is ONE twelve-product accumulation.
 SSA_DEV jac jac_madd(const jac &p, const aff &q) {
+#ifdef SSA_MADD_PLAIN
     fp6 Z1Z1 = f6_sqr(p.Z);
     fp6 U2 = f6_mul(q.x, Z1Z1);
     fp6 S2 = f6_mul(f6_mul(q.y, p.Z), Z1Z1);
     fp6 H = f6_sub(U2, p.X);
     fp6 R = f6_sub(S2, p.Y);
+#else
+    const fp6 Z1Z1 = f6_sqr(p.Z);
+    u64 zz7[6];
+    f6_mul_prescale(Z1Z1, zz7);
+    const fp6 H = f6_mul_subx_pre(q.x, Z1Z1, zz7, p.X);                   // U2 - X1
+    const fp6 R = f6_mul_subx_pre(f6_mul(q.y, p.Z), Z1Z1, zz7, p.Y);      // S2 - Y1
+#endif
     const bool p_inf = f6_is_zero(p.Z);
     const bool q_inf = f6_is_zero(q.x) && f6_is_zero(q.y);
     const bool h0 = f6_is_zero(H);
@@ -89,8 +105,13 @@ SSA_DEV jac jac_madd(const jac &p, const aff &q) {
     fp6 HHH = f6_mul(H, HH);
     fp6 V = f6_mul(p.X, HH);
     jac r;
+#ifdef SSA_MADD_PLAIN
     r.X = f6_sub(f6_sub(f6_sqr(R), HHH), f6_dbl(V));
     r.Y = f6_sub(f6_mul(R, f6_sub(V, r.X)), f6_mul(p.Y, HHH));
+#else
+    r.X = f6_sqr_subx_sub2y(R, HHH, V);
+    r.Y = f6_mul2_add(R, f6_sub(V, r.X), f6_neg(p.Y), HHH);
+#endif
     r.Z = f6_mul(p.Z, H);  // H == 0, R != 0  =>  Z3 = 0: p == -q gives the identity
     if (p_inf) {
         r.X = q.x;

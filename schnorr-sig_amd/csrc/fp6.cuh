@@ -183,6 +183,29 @@ SSA_FN fp6 f6_sqr_flat(u64 a0, u64 a1, u64 a2_, u64 a3, u64 a4, u64 a5) {
 }
 SSA_DEV fp6 f6_sqr(const fp6 &a) { return f6_sqr_flat(a.c[0], a.c[1], a.c[2], a.c[3], a.c[4], a.c[5]); }
 
+// the plain product and square as inlined blocks (no call, no argument moves): for the few hottest call sites only --
+// every inlined copy is ~3 KB of code (SSA_DBL_INLINE, measured in DESIGN.md)
+SSA_DEV fp6 f6_sqr_inl(const fp6 &a) {
+#ifdef SSA_F6_ASM
+    u64 a2[6], a7[6], a14[6];
+    a2[0] = 0ull;
+#pragma unroll
+    for (int j = 0; j < 3; j++) a7[j] = a14[j] = 0ull;
+#pragma unroll
+    for (int j = 1; j < 6; j++) a2[j] = fp_dbl(a.c[j]);
+#pragma unroll
+    for (int j = 3; j < 6; j++) {
+        a7[j] = fp_mul_small(a.c[j], 7u);
+        a14[j] = fp_dbl(a7[j]);
+    }
+    fp6 r;
+    f6_sqr_core_asm(a.c, a2, a7, a14, r.c);
+    return r;
+#else
+    return f6_sqr(a);
+#endif
+}
+
 // ---- products fused with the additions that follow them in the point formulas -------------------------------
 // r = a^2 (or a*b) + sum of small multiples of other elements, the linear terms added to the accumulator columns
 // before the single reduction (fp6_asm.inc, "fused linear terms": 4-6 instructions per coefficient and term instead
@@ -275,6 +298,31 @@ SSA_DEV fp6 f6_mul_subx(const fp6 &a, const fp6 &b, const fp6 &x) {
     return r;
 #else
     return f6_sub(f6_mul(a, b), x);
+#endif
+}
+
+// a*b - x with the prescaled second operand supplied by the caller (shared between several products by the same b)
+SSA_DEV fp6 f6_mul_subx_pre(const fp6 &a, const fp6 &b, const u64 (&b7)[6], const fp6 &x) {
+#ifdef SSA_F6_ASM
+    fp6 r;
+    f6_mul_subx_core_asm(a.c, b.c, b7, x.c, r.c);
+    return r;
+#else
+    (void)b7;
+    return f6_sub(f6_mul(a, b), x);
+#endif
+}
+// a*b + c*d: twelve products per coefficient in one accumulator, one reduction
+SSA_DEV fp6 f6_mul2_add(const fp6 &a, const fp6 &b, const fp6 &c, const fp6 &d) {
+#ifdef SSA_F6_ASM
+    u64 b7[6], d7[6];
+    f6_mul_prescale(b, b7);
+    f6_mul_prescale(d, d7);
+    fp6 r;
+    f6_mul2_add_core_asm(a.c, b.c, b7, c.c, d.c, d7, r.c);
+    return r;
+#else
+    return f6_add(f6_mul(a, b), f6_mul(c, d));
 #endif
 }
 

@@ -81,8 +81,14 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
-    for (auto &ev : ctx->copy_done)
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    for (auto &st : ctx->hash_stream)
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            ssa_ctx_destroy(ctx);
+            return SSA_ERR_HIP;
+        }
+    for (int i = 0; i < 8; i++)
+        if (hipEventCreateWithFlags(&ctx->copy_done[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->hash_done[i], hipEventDisableTiming) != hipSuccess) {
             ssa_ctx_destroy(ctx);
             return SSA_ERR_HIP;
         }
@@ -142,6 +148,10 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     for (auto &ev : ctx->copy_done)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->hash_done)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &st : ctx->hash_stream)
+        if (st) (void)hipStreamDestroy(st);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -325,8 +335,9 @@ struct PinnedRange {
 };
 
 // Large host-buffer batch: uploads in chunks on the copy stream, the challenge hashes of chunk c start as soon as
-// chunk c has arrived (they are 27 % of the work), one verification launch over the whole batch at the end --
-// the ladder kernel keeps its full-size grid, only the first chunk's upload is exposed.
+// chunk c has arrived (they are 27 % of the work) -- alternating between two streams, because a lane hashes for
+// ~4 ms and a launch's tail would otherwise idle most of the chip once per chunk -- and one verification launch
+// over the whole batch at the end: the ladder kernel keeps its full-size grid, only the first chunk's upload is exposed.
 static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                                  const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
                                  size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out, bool *used) {
@@ -369,14 +380,15 @@ static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_
         if (m_hi > m_lo)
             HIP_TRY(hipMemcpyAsync(d_msgs + m_lo, msgs + m_lo, m_hi - m_lo, hipMemcpyHostToDevice, ctx->copy_stream));
         HIP_TRY(hipEventRecord(ctx->copy_done[c], ctx->copy_stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->copy_done[c], 0));
+        hipStream_t hs = ctx->hash_stream[c & 1u];
+        HIP_TRY(hipStreamWaitEvent(hs, ctx->copy_done[c], 0));
         MsgView mv{msg_off ? d_msgs : d_msgs + lo * msg_stride, msg_off ? d_off + lo : nullptr, msg_stride, msg_len};
-        int rc = timed_launch(ctx, "ssa_k_hash", [&] {
-            hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(cnt, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
-                               (const u8 *)(d_sigs + 81 * lo), (const u8 *)(d_pks + 96 * lo), mv, cnt,
-                               (u64 *)ctx->ws_h.p + 4 * lo, (u8 *)nullptr, (const u32 *)nullptr, 0u);
-        });
-        if (rc) return rc;
+        hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(cnt, 256)), dim3(256), 0, hs, ctx->d_params,
+                           (const u8 *)(d_sigs + 81 * lo), (const u8 *)(d_pks + 96 * lo), mv, cnt,
+                           (u64 *)ctx->ws_h.p + 4 * lo, (u8 *)nullptr, (const u32 *)nullptr, 0u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ctx->hash_done[c], hs));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->hash_done[c], 0));
     }
     int rc = timed_launch(ctx, "ssa_k_verify", [&] {
         hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(n, ctx->verify_block)), dim3(ctx->verify_block), 0, ctx->stream,
@@ -829,7 +841,7 @@ extern "C" int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, con
 // ------------------------------------------------------------------ probes
 extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                                size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {
-    if (!ctx || !a || !out || n == 0 || op < 0 || op > 13) return SSA_ERR_ARG;
+    if (!ctx || !a || !out || n == 0 || op < 0 || op > 14) return SSA_ERR_ARG;
     if ((op == 0 || op == 3 || op == 4 || op == 5 || op >= 7) && !b) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const void *da, *db = nullptr;

@@ -61,8 +61,10 @@ struct ssa_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;        // uploads of the host-buffer entry points, overlapped with the kernels
     hipEvent_t copy_done[8] = {};             // one per upload chunk
+    hipStream_t hash_stream[2] = {};          // the chunks' hash launches alternate between two streams, so that the
+    hipEvent_t hash_done[8] = {};             //   tail of one launch (a lane hashes for ~4 ms) overlaps the next
     size_t pipeline_min_n = 1 << 17;          // host-buffer batches from this size on are uploaded in chunks
-    unsigned pipeline_chunks = 4;             // SSA_PIPELINE_CHUNKS overrides (1 = off)
+    unsigned pipeline_chunks = 8;             // SSA_PIPELINE_CHUNKS overrides (1 = off)
     DevParams *d_params = nullptr;
     u64 *d_gtab = nullptr;
     DevBuf ws_h, ws_tab, ws_fail;

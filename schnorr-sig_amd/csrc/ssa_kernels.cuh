@@ -834,7 +834,7 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
         for (int k = 0; k < 6; k++) po[k] = r.c[k];
         return;
     }
-    if (op >= 8 && op <= 13) {   // fused product + linear terms: a = (a, b), b = (x, y)
+    if (op >= 8 && op <= 14) {   // fused product + linear terms: a = (a, b), b = (x, y)
         fp6 u, v, x, y, r;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -848,7 +848,8 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
         else if (op == 10) r = f6_sqr_sub4x(u, x);
         else if (op == 11) r = f6_mul_sub8x(u, v, x);
         else if (op == 12) r = f6_mul_subx(u, v, x);
-        else r = f6_sqr_subx_sub2y(u, x, y);
+        else if (op == 13) r = f6_sqr_subx_sub2y(u, x, y);
+        else r = f6_mul2_add(u, v, x, y);
         r = f6_canon(r);
 #pragma unroll
         for (int k = 0; k < 6; k++) po[k] = r.c[k];

@@ -456,7 +456,8 @@ def test_fused_product_blocks(engine):
            10: lambda u, v, x, y: [(m - 4 * p_) % P for m, p_ in zip(mulmod(u, u), x)],
            11: lambda u, v, x, y: [(m - 8 * p_) % P for m, p_ in zip(mulmod(u, v), x)],
            12: lambda u, v, x, y: [(m - p_) % P for m, p_ in zip(mulmod(u, v), x)],
-           13: lambda u, v, x, y: [(m - p_ - 2 * q) % P for m, p_, q in zip(mulmod(u, u), x, y)]}
+           13: lambda u, v, x, y: [(m - p_ - 2 * q) % P for m, p_, q in zip(mulmod(u, u), x, y)],
+           14: lambda u, v, x, y: [(m + w) % P for m, w in zip(mulmod(u, v), mulmod(x, y))]}
     check = list(range(260)) + list(range(260, n, 13))
     for op, model in ops.items():
         got = engine.debug_arith(op, a, b, 6)

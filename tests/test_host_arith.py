@@ -37,6 +37,8 @@ def ha():
     lib.ha_fp_inv.argtypes = [C.c_uint64]
     lib.ha_inv_sbox.restype = C.c_uint64
     lib.ha_inv_sbox.argtypes = [C.c_uint64]
+    lib.ha_inv_sbox2.restype = C.c_uint64
+    lib.ha_inv_sbox2.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.ha_fp_mul_small.restype = C.c_uint64
     lib.ha_fp_mul_small.argtypes = [C.c_uint64, C.c_uint32]
     return lib
@@ -64,6 +66,9 @@ def test_fp_ops_loose_inputs(ha):
         if a % P:
             assert ha.ha_fp_inv(a) == pow(a, P - 2, P)
         assert ha.ha_inv_sbox(a) == pow(a, 10540996611094048183, P)
+        ob = C.c_uint64(0)
+        assert ha.ha_inv_sbox2(a, a ^ 0x5555, C.byref(ob)) == pow(a, 10540996611094048183, P)
+        assert ob.value == pow(a ^ 0x5555, 10540996611094048183, P)
 
 
 def test_fp6_ops(ha, oracle):

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds alternative libschnorr_sig_amd.so variants (compile-time switches of the kernels) under build/variants/
+# for A/B measurements on the GPU box:  SSA_LIB=build/variants/<name>.so python bench.py --skip-torsion-leg ...
+# usage: tools/build_variants.sh name1:"-DFLAG1 -DFLAG2" name2:"..."
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p build/variants
+for spec in "$@"; do
+    name=${spec%%:*}
+    flags=${spec#*:}
+    echo "building $name ($flags)"
+    hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared $flags -o build/variants/$name.so \
+        schnorr-sig_amd/csrc/ssa_api.hip schnorr-sig_amd/csrc/ssa_msm.hip &
+done
+wait
+ls -la build/variants

@@ -217,6 +217,19 @@ def mul_terms():
     return out
 
 
+def mul2_terms():
+    """c_k of a * b + c * d: the twelve products of both in one accumulator (second pair: operands c, e = d, t = 7 d)"""
+    out = []
+    for k in range(6):
+        t = []
+        for i in range(6):
+            t.append(("a%d" % i, "b%d" % (k - i)) if i <= k else ("a%d" % i, "s%d" % (k + 6 - i)))
+        for i in range(6):
+            t.append(("c%d" % i, "e%d" % (k - i)) if i <= k else ("c%d" % i, "t%d" % (k + 6 - i)))
+        out.append(t)
+    return out
+
+
 def sqr_terms():
     """direct i + j = k (i <= j): a_i * (a_j | 2a_j); wrapped i + j = k + 6: a_i * (7a_j | 14a_j)"""
     out = []
@@ -308,6 +321,8 @@ def main():
             ("f6_sqr_sub4x_core_asm", sqr_terms(), sqr_in + [("x", "x")], [(-1, 4, "x")], "r = a^2 - 4 x"),
             ("f6_mul_sub8x_core_asm", mul_terms(), mul_in + [("x", "x")], [(-1, 8, "x")], "r = a * b - 8 x"),
             ("f6_mul_subx_core_asm", mul_terms(), mul_in + [("x", "x")], [(-1, 1, "x")], "r = a * b - x"),
+            ("f6_mul2_add_core_asm", mul2_terms(), mul_in + [("c", "c"), ("d", "e"), ("d7", "t")], [],
+             "r = a * b + c * d; b7[j] = 7 b[j], d7[j] = 7 d[j] (j = 1..5)"),
             ("f6_sqr_subx_sub2y_core_asm", sqr_terms(), sqr_in + [("x", "x"), ("y", "y")], [(-1, 1, "x"), (-1, 2, "y")],
              "r = a^2 - x - 2 y")):
         blk, nl, nmad = emit(nm, terms, ins, doc, ex)

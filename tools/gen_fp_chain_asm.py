@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generates schnorr-sig_amd/csrc/fp_chain_asm.inc: chains of Goldilocks squarings for TWO independent values at a
+time, one inline-asm loop -- the shape of the Rescue inverse S-box x^(1/7) (63 squarings + 9 products per state
+element, reference hash::rescue_64_12_8 called at src/signature.rs:303), 58 of whose squarings sit in five
+`square n times, multiply once` runs.
+
+Why: the kernel is bound by VALU ISSUE, and on gfx950 every VALU instruction in a stream that contains the 64-bit
+multiplier costs about 4 cycles per wave whatever it is (tools/isa_probe, DESIGN.md "instruction cost table"), so what
+counts is the number of instructions.  hipcc's squaring is 22 VALU instructions + 2 s_nop: it detects the borrow and
+the carry of the reduction with separate 64-bit compares (v_cmp_lt_u64 + v_mov to build the zero-extended operand)
+although v_subbrev / v_addc already deliver them, and it pads the two VCC hazards of its single dependent chain.
+Here: 17 instructions per squaring, carries in SGPR pairs, and the second value's instructions fill the two wait
+states gfx950 needs between a VALU write of an SGPR and the VALU read of it (a list scheduler below places them).
+Two values only: six at a time (round 1) cost registers, occupancy fell from 4 to 3 waves per SIMD and a lone wave
+issues only every ~6 cycles -- slower in spite of fewer instructions.
+
+One squaring, a = a0 + 2^32 a1 (three multiplies, fp.cuh fp_sqr3):
+    t0 = a0^2;  u = a0 a1 + (t0 >> 33);  hi = a1^2 + (u >> 31);  lo = (t0 mod 2^33) | (u mod 2^31) << 33
+reduction (fp_reduce128): r = lo - hi.hi [borrow: + p] + EPS * hi.lo [carry: + EPS]
+"""
+import os
+
+# fixed registers per chain (c = 0, 1); all above the compiler's own allocation for ssa_k_hash, all below v128
+BASE = 80
+
+
+def regs(c):
+    o = BASE + 2 * c
+
+    def pair(k):
+        return o + 4 * k
+
+    return {"X": pair(0), "T": pair(1), "A": pair(2), "U": pair(3), "H": pair(4), "R": pair(5), "M": pair(6), "E": pair(7),
+            "C": pair(8), "S": 20 + 2 * c}
+
+
+DUMMY = "s[24:25]"     # carry-outs nobody reads
+
+
+def vp(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def sp(r):
+    return "s[%d:%d]" % (r, r + 1)
+
+
+def square(c):
+    """(text, sgprs read, sgprs written) of one squaring of chain c, in dependency order"""
+    g = regs(c)
+    X, T, A, U, H, R, M, E, C, S = (g[k] for k in "XTAUHRMECS")
+    s = sp(S)
+    return [
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, X), [], []),
+        ("v_lshrrev_b32 v%d, 1, v%d" % (A, T + 1), [], []),                       # (t0 >> 33); v[A+1] stays 0
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), DUMMY, X, X + 1, vp(A)), [], []),
+        ("v_and_b32 v%d, 1, v%d" % (T + 1, T + 1), [], []),
+        ("v_lshrrev_b64 %s, 31, %s" % (vp(H), vp(U)), [], []),
+        ("v_lshl_or_b32 v%d, v%d, 1, v%d" % (T + 1, U, T + 1), [], []),           # lo = v[T:T+1]
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, X + 1, vp(H)), [], []),   # hi
+        ("v_sub_co_u32 v%d, %s, v%d, v%d" % (R, s, T, H + 1), [], [S]),
+        ("v_mad_u64_u32 %s, %s, v%d, -1, 0" % (vp(M), DUMMY, H), [], []),          # EPS * hi.lo
+        ("v_subbrev_co_u32 v%d, %s, 0, v%d, %s" % (R + 1, s, T + 1, s), [S], [S]),
+        ("v_cndmask_b32 v%d, 0, 1, %s" % (E, s), [S], []),                        # borrow ? p : 0
+        ("v_cndmask_b32 v%d, 0, -1, %s" % (E + 1, s), [S], []),
+        ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(R), vp(E), vp(R)), [], []),
+        ("v_add_co_u32 v%d, %s, v%d, v%d" % (X, s, R, M), [], [S]),
+        ("v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (X + 1, s, R + 1, M + 1, s), [S], [S]),
+        ("v_cndmask_b32 v%d, 0, -1, %s" % (C, s), [S], []),                       # carry ? EPS : 0; v[C+1] stays 0
+        ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(X), vp(C), vp(X)), [], []),
+    ]
+
+
+def _regs_of(text):
+    """(vgprs read, vgprs written, sgpr pairs read, sgpr pairs written) of one instruction, by operand position"""
+    import re
+    mnem, rest = text.split(None, 1)
+    ops = [o.strip() for o in rest.split(",")]
+
+    def expand(o):
+        m = re.match(r"v\[(\d+):(\d+)\]$", o)
+        if m:
+            return [("v", r) for r in range(int(m.group(1)), int(m.group(2)) + 1)]
+        m = re.match(r"v(\d+)$", o)
+        if m:
+            return [("v", int(m.group(1)))]
+        m = re.match(r"s\[(\d+):(\d+)\]$", o)
+        if m:
+            return [("s", int(m.group(1)))]
+        return []
+    n_dst = 2 if mnem in ("v_mad_u64_u32", "v_sub_co_u32", "v_subbrev_co_u32", "v_add_co_u32", "v_addc_co_u32") else 1
+    wr = [r for o in ops[:n_dst] for r in expand(o)]
+    rd = [r for o in ops[n_dst:] for r in expand(o)]
+    return rd, wr
+
+
+def schedule(chains):
+    """list scheduling of the chains' instructions together: dependencies from the registers (RAW, WAW, WAR), an
+    SGPR pair written at position i is readable at i + 3 at the earliest (two wait states), longest remaining path
+    first; s_nop only where nothing else is ready"""
+    ins = [t for ch in chains for (t, _, _) in ch]
+    info = [_regs_of(t) for t in ins]
+    n = len(ins)
+    preds = [set() for _ in range(n)]
+    for j in range(n):
+        rdj, wrj = info[j]
+        for i in range(j):
+            rdi, wri = info[i]
+            if set(wri) & set(rdj) or set(wri) & set(wrj) or set(rdi) & set(wrj):
+                if ("s", 24) in (set(wri) & set(wrj)) and not (set(wri) & set(rdj)) and not ((set(wri) & set(wrj)) - {("s", 24)}) \
+                        and not (set(rdi) & set(wrj)):
+                    continue            # the dummy carry-out pair orders nothing
+                preds[j].add(i)
+    height = [1] * n
+    for j in range(n - 1, -1, -1):
+        for i in preds[j]:
+            height[i] = max(height[i], height[j] + 1)
+    placed_at = {}
+    out = []
+    last_sgpr_write = {}
+    while len(placed_at) < n:
+        best = None
+        for j in range(n):
+            if j in placed_at or any(i not in placed_at for i in preds[j]):
+                continue
+            rd, wr = info[j]
+            if any(r[0] == "s" and r[1] != 24 and len(out) - last_sgpr_write.get(r, -10) < 3 for r in rd):
+                continue
+            if best is None or height[j] > height[best]:
+                best = j
+        if best is None:
+            out.append("s_nop 0")
+            continue
+        out.append(ins[best])
+        placed_at[best] = len(out) - 1
+        for r in info[best][1]:
+            if r[0] == "s":
+                last_sgpr_write[r] = len(out) - 1
+    return out
+
+
+def main():
+    body = schedule([square(0), square(1)])
+    n_valu = sum(1 for ln in body if ln.startswith("v_"))
+    n_nop = sum(1 for ln in body if ln.startswith("s_nop"))
+    g0, g1 = regs(0), regs(1)
+    lines = []
+    lines.append("// generated by tools/gen_fp_chain_asm.py -- do not edit (see that file for the design notes)")
+    lines.append("// x <- x^(2^n), y <- y^(2^n) (mod p, loose in / loose out), n >= 1: %d VALU instructions and %d s_nop per"
+                 % (n_valu, n_nop))
+    lines.append("// pair of squarings.")
+    lines.append("SSA_DEV void fp_sqr2_n_asm(u64 &x, u64 &y, int n) {")
+    lines.append("    u32 x0 = lo32(x), x1 = hi32(x), y0 = lo32(y), y1 = hi32(y);")
+    lines.append("    asm volatile(")
+    pre = ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
+           "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
+    for g in (g0, g1):
+        pre += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1)]
+    pre += ["s_mov_b32 s26, %[n]"]
+    for ln in pre:
+        lines.append('        "%s\\n\\t"' % ln)
+    lines.append('        "L_fp_sqr2_%=:\\n\\t"')
+    for ln in body:
+        lines.append('        "%s\\n\\t"' % ln)
+    for ln in ["s_sub_u32 s26, s26, 1", "s_cmp_lg_u32 s26, 0", "s_cbranch_scc1 L_fp_sqr2_%="]:
+        lines.append('        "%s\\n\\t"' % ln)
+    post = ["v_mov_b32 %%[x0], v%d" % g0["X"], "v_mov_b32 %%[x1], v%d" % (g0["X"] + 1),
+            "v_mov_b32 %%[y0], v%d" % g1["X"], "v_mov_b32 %%[y1], v%d" % (g1["X"] + 1)]
+    for i, ln in enumerate(post):
+        lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(post) else ""))
+    lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1)')
+    lines.append('        : [n] "s"(n)')
+    used = sorted(set(range(BASE, BASE + 4 * 9)))
+    clob = ['"v%d"' % r for r in used] + ['"s20"', '"s21"', '"s22"', '"s23"', '"s24"', '"s25"', '"s26"', '"scc"', '"vcc"']
+    lines.append("        : " + ", ".join(clob) + ");")
+    lines.append("    x = mk64(x0, x1);")
+    lines.append("    y = mk64(y0, y1);")
+    lines.append("}")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc",
+                        "fp_chain_asm.inc")
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("wrote %s: %d VALU + %d s_nop per pair of squarings" % (path, n_valu, n_nop))
+
+
+if __name__ == "__main__":
+    main()

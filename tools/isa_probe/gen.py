@@ -128,6 +128,30 @@ probe("mad4_then_add4", ["v_mad_u64_u32 v[20:21], vcc, v10, v11, v[12:13]", "v_m
                          "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11", "v_add_u32 v38, v10, v12", "v_add_u32 v39, v10, v12"])
 probe("mad_addc_pairs", ["v_mad_u64_u32 v[20:21], s[40:41], v10, v11, v[20:21]", "v_mad_u64_u32 v[22:23], s[42:43], v10, v12, v[22:23]",
                          "v_addc_co_u32 v36, s[40:41], 0, v36, s[40:41]", "v_addc_co_u32 v37, s[42:43], 0, v37, s[42:43]"])
+# run lengths: N multiply-accumulates (carry-out to N distinct SGPR pairs), then the N carry adds -- does the switch
+# between the multiplier pipe and the plain ALU cost issue slots?  (R = 48 copies of the whole group.)
+for _n in (1, 2, 4, 8, 12):
+    _pat = []
+    for _j in range(_n):
+        _pat.append("v_mad_u64_u32 v[%d:%d], s[%d:%d], v10, v11, v[%d:%d]" % (20 + 2 * (_j % 8), 21 + 2 * (_j % 8), 38 + 2 * _j, 39 + 2 * _j, 20 + 2 * (_j % 8), 21 + 2 * (_j % 8)))
+    for _j in range(_n):
+        _pat.append("v_addc_co_u32 v%d, s[%d:%d], 0, v%d, s[%d:%d]" % (36 + (_j % 4), 38 + 2 * _j, 39 + 2 * _j, 36 + (_j % 4), 38 + 2 * _j, 39 + 2 * _j))
+    if _n == 1:
+        _pat.insert(1, "s_nop 1")
+    elif _n == 2:
+        _pat.insert(2, "s_nop 0")
+    probe("run%d_mad_then_addc" % _n, _pat, n_instr=2 * _n)
+for _n in (2, 4, 8):
+    _pat = ["v_mad_u64_u32 v[%d:%d], vcc, v10, v11, v[12:13]" % (20 + 2 * (_j % 8), 21 + 2 * (_j % 8)) for _j in range(_n)]
+    _pat += ["v_add_u32 v%d, v10, v11" % (36 + (_j % 4)) for _j in range(_n)]
+    probe("run%d_mad_then_add" % _n, _pat)
+for _n in (2, 4, 8):
+    _pat = ["v_mad_u64_u32 v[%d:%d], vcc, v10, v11, v[12:13]" % (20 + 2 * (_j % 8), 21 + 2 * (_j % 8)) for _j in range(_n)]
+    _pat += ["v_lshl_add_u64 v[%d:%d], v[10:11], 0, v[12:13]" % (36 + 2 * (_j % 2), 37 + 2 * (_j % 2)) for _j in range(_n)]
+    probe("run%d_mad_then_lshladd64" % _n, _pat)
+probe("cmp64_cndmask_lshladd", ["v_lshl_add_u64 v[20:21], v[10:11], 0, v[12:13]", "v_cmp_lt_u64 s[40:41], v[20:21], v[10:11]",
+                                 "v_lshl_add_u64 v[22:23], v[14:15], 0, v[12:13]", "v_cmp_lt_u64 s[42:43], v[22:23], v[14:15]",
+                                 "v_cndmask_b32 v36, 0, -1, s[40:41]", "v_cndmask_b32 v37, 0, -1, s[42:43]"])
 probe("ds_read_b128_plus_4add", ["ds_read_b128 v[{q}:{q3}], v18", "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11", "v_add_u32 v38, v10, v12", "v_add_u32 v39, v10, v12"], n_instr=5, setup="lds")
 
 
