@@ -51,8 +51,12 @@ W_VERIFY_KEYED = W_LADDER + W_BASE + F6_MUL + F6_SQR   # keyed context: table an
 W_TORSION = W_LADDER
 W_HASH = 4 * 7 * (12 * 4 + 12 * 72 + 2 * 144)   # 4 permutations x 7 rounds (80-byte message)
 BYTES_PER_VERIFY = 81 + 96 + 80 + 1             # algorithmic HBM bytes
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9            # MI355X_MICROARCH.md: 256 CU x 4 SIMD-32 x 2.4 GHz
-PEAK_FPMUL = VALU_LANE_OPS / 16                 # 4 quarter-rate v_mad_u64_u32 per product, nothing else
+# Peak of the multiplier, measured in round 2 (tools/isa_probe, DESIGN.md "instruction cost table"): v_mad_u64_u32
+# issues once per ~4 cycles per wave64 (4.1-4.7 measured; the class of v_fma_f64 -- 16 lanes per clock), NOT the
+# 8 cycles ("quarter rate") round 1 assumed.  Peak = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles x 64 lanes / 4 multiplies
+# per 64x64 product, and nothing but multiplies.
+PEAK_FPMUL = 256 * 4 * 2.4e9 / 4 * 64 / 4       # 9.83e12 Fp-mul/s
+PEAK_FPMUL_R01 = 256 * 4 * 32 * 2.4e9 / 16      # round 1's figure (8 cycles per multiply), kept for continuity
 PEAK_HBM_GBPS = 8000.0
 LIB = os.environ.get("SSA_LIB") or os.path.join(ROOT, "schnorr-sig_amd", "csrc", "libschnorr_sig_amd.so")
 
@@ -477,13 +481,16 @@ def main():
             "config4_strong": config4,
             "roofline": {
                 "bound": "valu",
-                "bound_note": "64-bit integer VALU (v_mad_u64_u32), neither hbm nor mfma: SURVEY.md 8(d); peak = "
-                              "256 CU x 4 SIMD x 32 lanes x 2.4 GHz / 16 lane-slots per 64x64 product",
+                "bound_note": "64-bit integer VALU issue (v_mad_u64_u32), neither hbm nor mfma: SURVEY.md 8(d); peak = "
+                              "256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 multiply (measured 4.1-4.7, tools/isa_probe) "
+                              "x 64 lanes / 4 multiplies per 64x64 product -- TWICE round 1's peak, which assumed a "
+                              "quarter-rate multiplier; frac_r01_basis divides by the old peak for continuity",
                 "kernel": "ssa_k_verify",
                 "achieved": achieved / 1e9,
                 "peak": PEAK_FPMUL / 1e9,
                 "unit": "GFp-mul/s",
                 "frac": achieved / PEAK_FPMUL,
+                "frac_r01_basis": achieved / PEAK_FPMUL_R01,
                 "work_per_unit": w_kernel,
                 "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
@@ -600,7 +607,8 @@ def keyed_leg(torch, eng, dev, g, n, n_keys=64):
     return {"workload": "%d signatures by %d signers (keyed context), Signature::verify semantics" % (n, n_keys),
             "verifications_per_sec": n / dt, "ms_per_batch": dt * 1e3, "keyset_create_ms": create_ms,
             "kernel_ms": k_ms, "rejected": rej,
-            "roofline_frac": (W_VERIFY_KEYED * n / (k_ms * 1e-3) / PEAK_FPMUL) if k_ms > 0 else None}
+            "roofline_frac": (W_VERIFY_KEYED * n / (k_ms * 1e-3) / PEAK_FPMUL) if k_ms > 0 else None,
+            "roofline_frac_r01_basis": (W_VERIFY_KEYED * n / (k_ms * 1e-3) / PEAK_FPMUL_R01) if k_ms > 0 else None}
 
 
 def cpu_baseline(np, sigs, pks, msgs, gpu_status_batch_semantics, m):
