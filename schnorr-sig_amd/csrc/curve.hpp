@@ -7,7 +7,7 @@
 // (adversarial e can steer the accumulator onto a table point); doublings need no special
 // case (Y == 0 or Z == 0 both give Z3 == 0).
 #pragma once
-#include "fp6.cuh"
+#include "fp6.hpp"
 
 namespace ssa {
 

@@ -4,7 +4,7 @@
 // src/batch.rs:104).  The 2-Sylow subgroup of Fp3* has order 2^32 and lies inside Fp*, so the
 // Tonelli-Shanks discrete logarithm runs on plain Goldilocks elements.
 #pragma once
-#include "fp6.cuh"
+#include "fp6.hpp"
 
 namespace ssa {
 

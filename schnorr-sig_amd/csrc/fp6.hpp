@@ -9,7 +9,7 @@
 // the C++ formulation below, which stays as the host build (tests/csrc/host_arith.cpp) and as the
 // -DSSA_NO_F6_ASM fallback: ssa_k_verify 41.25 -> 38.85 ms at 2^20, lazy-Fp6 probe 2.80 -> 2.96e12 Fp-mul/s.
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 namespace ssa {
 

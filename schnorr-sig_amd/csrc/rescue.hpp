@@ -3,7 +3,7 @@
 // (src/signature.rs:274-306).  All constants come from the parameter blob (ssa_params): the
 // upstream values are unpinned, so nothing here is hard-coded except alpha = 7.
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 namespace ssa {
 

@@ -1,4 +1,4 @@
-// C ABI (include/schnorr_sig_amd.h) over the HIP kernels in ssa_kernels.cuh.
+// C ABI (include/schnorr_sig_amd.h) over the HIP kernels in ssa_kernels.hpp.
 // No CPU compute path exists here: every entry point launches kernels on the context's
 // device or fails with an SSA_ERR_* code.
 #define SSA_KERNELS_DEFINE 1

@@ -1,6 +1,6 @@
 // Wave-cooperative arithmetic: ONE WAVE works on ONE point / ONE signature.
 //
-// The per-lane kernels (ssa_kernels.cuh) need ~65 k lanes to fill the chip and take 5-8 ms per call however
+// The per-lane kernels (ssa_kernels.hpp) need ~65 k lanes to fill the chip and take 5-8 ms per call however
 // small the batch is, because a lane runs its ~330 point operations serially.  Here a wave shares the work of
 // one point operation: Fp6 values live in LDS slots; the independent products of a formula run side by side
 // (twelve lanes per product, one LDS round trip per round) with the formula's additions folded into the tail
@@ -11,7 +11,7 @@
 // Every function here must be called by ALL 64 lanes of the wave that owns the working set; Fp6 values are
 // LDS slots addressed by index, booleans returned are wave-uniform.
 #pragma once
-// (included at the end of ssa_kernels.cuh: uses its byte loaders, msg_felt and status codes)
+// (included at the end of ssa_kernels.hpp: uses its byte loaders, msg_felt and status codes)
 
 namespace ssa {
 

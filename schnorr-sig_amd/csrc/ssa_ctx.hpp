@@ -2,7 +2,7 @@
 // (ssa_api.hip: per-lane verification path; ssa_msm.hip: MSM-form batch verification).
 #pragma once
 #include "../../include/schnorr_sig_amd.h"
-#include "ssa_kernels.cuh"
+#include "ssa_kernels.hpp"
 
 #include <hip/hip_runtime.h>
 

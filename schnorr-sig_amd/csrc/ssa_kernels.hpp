@@ -15,9 +15,9 @@
 //                           lane's gather of one entry is six 16-byte loads from one cache line
 //   gtab    16 x 65536 x 12 u64 affine multiples d*2^(16w)*G (100 MB, Infinity-Cache resident)
 #pragma once
-#include "curve.cuh"
-#include "fp3.cuh"
-#include "rescue.cuh"
+#include "curve.hpp"
+#include "fp3.hpp"
+#include "rescue.hpp"
 
 namespace ssa {
 
@@ -124,7 +124,7 @@ ssa_k_hash(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs,
            const u8 *__restrict__ pks, MsgView mv, size_t n, u64 *__restrict__ h_out,
            u8 *__restrict__ digest_out, const u32 *__restrict__ key_idx, u32 n_keys) {
     __shared__ u64 lds[RS_LDS_U64];
-    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.cuh)
+    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.hpp)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool ok = true;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256)
 ssa_k_rescue(const DevParams *__restrict__ prm, const u64 *__restrict__ felts, u32 per_row,
              size_t n, u64 *__restrict__ out) {
     __shared__ u64 lds[RS_LDS_U64];
-    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.cuh)
+    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.hpp)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 *row = felts + (size_t)per_row * i;
@@ -706,7 +706,7 @@ ssa_k_sign(const DevParams *__restrict__ prm, const u64 *__restrict__ gtab,
            const u8 *__restrict__ sks, const u8 *__restrict__ nonces, MsgView mv, size_t n,
            u8 *__restrict__ pks_out, u8 *__restrict__ sigs_out) {
     __shared__ u64 lds[RS_LDS_U64];
-    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.cuh)
+    u64 *A = lds + threadIdx.x, *B = A;   // the MDS layer works in place (rescue.hpp)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const sc256 sk = sc_reduce256(ld_sc(sks + 32 * i));
@@ -981,7 +981,7 @@ __global__ void __launch_bounds__(256) ssa_k_f6mul_bench(u64 *out, u64 seed, int
 
 // wave-cooperative path (device code only; the host-compiled unit tests leave it out)
 #ifndef SSA_NO_COOP
-#include "ssa_coop.cuh"
+#include "ssa_coop.hpp"
 
 #ifndef SSA_NO_KERNELS
 namespace ssa {

@@ -269,7 +269,7 @@ msm_k_chacha20(ChaChaKey kn, u32 counter0, size_t n_blocks, u32 *__restrict__ ou
 // ---- the one sequential chain of the reduction ---------------------------------------------------
 // left = sum_j 2^(c j) W_j by Horner's rule: (windows - 1) x (c doublings + one addition), a chain of ~240
 // dependent doublings.  A lone lane ran it at ~80 us per doubling; here wave 0 of the block works on the
-// one point (wave-cooperative Fp6 arithmetic, ssa_coop.cuh: ~2.5 us per doubling) while wave 1 adds up
+// one point (wave-cooperative Fp6 arithmetic, ssa_coop.hpp: ~2.5 us per doubling) while wave 1 adds up
 // lin = sum of the blocks' partial sums and computes right = [lin] G from the comb table.
 // Verdict: x-only comparison, left.get_x() == right.get_x() (src/batch.rs:98-100, :125-129).
 __global__ void __launch_bounds__(128)

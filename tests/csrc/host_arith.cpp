@@ -1,12 +1,12 @@
 // Host-side compile of the device arithmetic headers (tests only).  The limb logic of
-// fp.cuh / fp6.cuh / curve.cuh / rescue.cuh is plain integer C++ apart from one inline-asm
+// fp.hpp / fp6.hpp / curve.hpp / rescue.hpp is plain integer C++ apart from one inline-asm
 // multiply-accumulate that has a C twin, so it can be unit-tested against the oracle on a
 // machine without a GPU.  The shipped library never executes this code on the CPU.
 //   hipcc --cuda-host-only -x hip -O2 -shared -fPIC host_arith.cpp -o libhost_arith.so
 #define SSA_NO_KERNELS 1
 #define SSA_NO_COOP 1
 #include <cstring>
-#include "../../schnorr-sig_amd/csrc/ssa_kernels.cuh"
+#include "../../schnorr-sig_amd/csrc/ssa_kernels.hpp"
 
 using namespace ssa;
 

@@ -24,7 +24,7 @@ def ha():
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
     csrc = os.path.join(os.path.dirname(HERE), "schnorr-sig_amd", "csrc")
-    deps = [SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".cuh")]
+    deps = [SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-x", "hip", "-O2", "-shared", "-fPIC", SRC, "-o", LIB])
     lib = C.CDLL(LIB)

@@ -14,7 +14,7 @@ states gfx950 needs between a VALU write of an SGPR and the VALU read of it (a l
 Two values only: six at a time (round 1) cost registers, occupancy fell from 4 to 3 waves per SIMD and a lone wave
 issues only every ~6 cycles -- slower in spite of fewer instructions.
 
-One squaring, a = a0 + 2^32 a1 (three multiplies, fp.cuh fp_sqr3):
+One squaring, a = a0 + 2^32 a1 (three multiplies, fp.hpp fp_sqr3):
     t0 = a0^2;  u = a0 a1 + (t0 >> 33);  hi = a1^2 + (u >> 31);  lo = (t0 mod 2^33) | (u mod 2^31) << 33
 reduction (fp_reduce128): r = lo - hi.hi [borrow: + p] + EPS * hi.lo [carry: + EPS]
 """
