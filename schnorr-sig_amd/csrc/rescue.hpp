@@ -50,43 +50,23 @@ SSA_DEV u64 inv_sbox(u64 x) {
     return fp_mul(a, b);
 }
 
-// Two state elements at a time: the five `square n times, multiply once` runs of the chain (58 of its 63
-// squarings) go through one asm loop that squares both values with 17 instructions each instead of hipcc's 22 + 2
-// s_nop (fp_chain_asm.inc, tools/gen_fp_chain_asm.py); the rest is the plain code above.
+// Two state elements at a time, the whole chain of both in ONE asm block (fp_chain_asm.inc,
+// tools/gen_fp_chain_asm.py): 17 instructions per squaring and 20 per product instead of hipcc's 22-26 + s_nop
+// padding, the two values interleaved by a list scheduler so that the SGPR carries get their wait states.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SSA_NO_FP_CHAIN_ASM)
 #include "fp_chain_asm.inc"
-SSA_DEV void fp_sqr2_n(u64 &x, u64 &y, int n) { fp_sqr2_n_asm(x, y, n); }
+SSA_DEV void inv_sbox2(u64 &x, u64 &y) { inv_sbox2_asm(x, y); }
+SSA_DEV void sbox2(u64 &x, u64 &y) { sbox2_asm(x, y); }
 #else
-SSA_DEV void fp_sqr2_n(u64 &x, u64 &y, int n) {
-    for (int i = 0; i < n; i++) {
-        x = fp_sqr(x);
-        y = fp_sqr(y);
-    }
+SSA_DEV void inv_sbox2(u64 &x, u64 &y) {
+    x = inv_sbox(x);
+    y = inv_sbox(y);
+}
+SSA_DEV void sbox2(u64 &x, u64 &y) {
+    x = sbox(x);
+    y = sbox(y);
 }
 #endif
-SSA_DEV void inv_sbox2(u64 &x, u64 &y) {
-    const u64 t1x = fp_sqr(x), t1y = fp_sqr(y);
-    const u64 t2x = fp_sqr(t1x), t2y = fp_sqr(t1y);
-    u64 ax = t2x, ay = t2y;
-    fp_sqr2_n(ax, ay, 3);
-    const u64 t3x = fp_mul(ax, t2x), t3y = fp_mul(ay, t2y);
-    ax = t3x; ay = t3y;
-    fp_sqr2_n(ax, ay, 6);
-    const u64 t4x = fp_mul(ax, t3x), t4y = fp_mul(ay, t3y);
-    ax = t4x; ay = t4y;
-    fp_sqr2_n(ax, ay, 12);
-    ax = fp_mul(ax, t4x); ay = fp_mul(ay, t4y);                  // t5
-    fp_sqr2_n(ax, ay, 6);
-    const u64 t6x = fp_mul(ax, t3x), t6y = fp_mul(ay, t3y);
-    ax = t6x; ay = t6y;
-    fp_sqr2_n(ax, ay, 31);
-    ax = fp_mul(ax, t6x); ay = fp_mul(ay, t6y);                  // t7
-    ax = fp_mul(fp_sqr(ax), t6x); ay = fp_mul(fp_sqr(ay), t6y);
-    ax = fp_sqr(fp_sqr(ax)); ay = fp_sqr(fp_sqr(ay));
-    const u64 bx = fp_mul(fp_mul(t1x, t2x), x), by = fp_mul(fp_mul(t1y, t2y), y);
-    x = fp_mul(ax, bx);
-    y = fp_mul(ay, by);
-}
 
 // The 12-felt sponge state of a lane lives in LDS ("LDS-staged"): element i of lane t is
 // st[i * RS_STRIDE + t], so dynamic indexing costs a ds_read/ds_write instead of forcing the
@@ -134,7 +114,8 @@ SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ pr
     for (u32 r = 0; r < nr; r++) {
 #pragma unroll 1
         for (int i = 0; i < 6; i++) {  // two independent chains per iteration
-            const u64 x = sbox(A[i * RS_STRIDE]), y = sbox(A[(i + 6) * RS_STRIDE]);
+            u64 x = A[i * RS_STRIDE], y = A[(i + 6) * RS_STRIDE];
+            sbox2(x, y);
             A[i * RS_STRIDE] = x;
             A[(i + 6) * RS_STRIDE] = y;
         }

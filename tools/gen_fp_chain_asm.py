@@ -21,7 +21,8 @@ reduction (fp_reduce128): r = lo - hi.hi [borrow: + p] + EPS * hi.lo [carry: + E
 import os
 
 # fixed registers per chain (c = 0, 1); all above the compiler's own allocation for ssa_k_hash, all below v128
-BASE = 80
+BASE = 72
+N_PAIRS = 14      # X T A U H R M E C + saved values V0..V4
 
 
 def regs(c):
@@ -30,8 +31,11 @@ def regs(c):
     def pair(k):
         return o + 4 * k
 
-    return {"X": pair(0), "T": pair(1), "A": pair(2), "U": pair(3), "H": pair(4), "R": pair(5), "M": pair(6), "E": pair(7),
-            "C": pair(8), "S": 20 + 2 * c}
+    g = {"X": pair(0), "T": pair(1), "A": pair(2), "U": pair(3), "H": pair(4), "R": pair(5), "M": pair(6), "E": pair(7),
+         "C": pair(8), "S": 20 + 2 * c}
+    for k in range(5):
+        g["V%d" % k] = pair(9 + k)
+    return g
 
 
 DUMMY = "s[24:25]"     # carry-outs nobody reads
@@ -69,6 +73,94 @@ def square(c):
         ("v_cndmask_b32 v%d, 0, -1, %s" % (C, s), [S], []),                       # carry ? EPS : 0; v[C+1] stays 0
         ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(X), vp(C), vp(X)), [], []),
     ]
+
+
+def reduce_tail(c):
+    """lo = v[T:T+1], hi = v[H:H+1] -> X (the last ten instructions of square())"""
+    return square(c)[7:]
+
+
+def multiply(c, saved):
+    """X <- X * saved value (register pair name "V0".."V4"): four multiplies, operand-scanning with the addends in
+    zero-extended pairs (v[A+1] and v[C+1] hold 0), then the reduction"""
+    g = regs(c)
+    X, T, A, U, H, C, E, V = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved]
+    head = [
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),              # t0 = x0 s0
+        ("v_mov_b32 v%d, v%d" % (A, T + 1), [], []),
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), DUMMY, X, V + 1, vp(A)), [], []),  # t1 = x0 s1 + hi(t0)
+        ("v_mov_b32 v%d, v%d" % (A, U), [], []),
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V, vp(A)), [], []),  # t2 = x1 s0 + lo(t1)
+        ("v_mov_b32 v%d, v%d" % (T + 1, H), [], []),                                       # lo = (lo(t0), lo(t2))
+        ("v_mov_b32 v%d, v%d" % (A, U + 1), [], []),
+        ("v_mov_b32 v%d, v%d" % (C, H + 1), [], []),
+        # hi(t1) + hi(t2) < 2^33 into the E pair (free until the reduction; v[A+1], v[C+1] must stay 0)
+        ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(A), vp(C)), [], []),
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V + 1, vp(E)), [], []),   # hi
+    ]
+    return head + reduce_tail(c)
+
+
+def copy(c, dst, src):
+    g = regs(c)
+    return [("v_mov_b32 v%d, v%d" % (g[dst], g[src]), [], []), ("v_mov_b32 v%d, v%d" % (g[dst] + 1, g[src] + 1), [], [])]
+
+
+# the chains as programs: ("sq", n) n squarings (a loop when n > 2), ("mul", V), ("cp", dst, src)
+INV_SBOX = [("cp", "V0", "X"), ("sq", 1), ("cp", "V1", "X"), ("sq", 1), ("cp", "V2", "X"),        # x, x^2, x^4
+            ("sq", 3), ("mul", "V2"), ("cp", "V3", "X"),                                         # t3
+            ("sq", 6), ("mul", "V3"), ("cp", "V4", "X"),                                         # t4
+            ("sq", 12), ("mul", "V4"),                                                           # t5
+            ("sq", 6), ("mul", "V3"), ("cp", "V4", "X"),                                         # t6
+            ("sq", 31), ("mul", "V4"),                                                           # t7
+            ("sq", 1), ("mul", "V4"), ("sq", 2), ("cp", "V4", "X"),                              # a
+            ("cp", "X", "V1"), ("mul", "V2"), ("mul", "V0"), ("mul", "V4")]                      # a * (x^2 x^4 x)
+SBOX = [("cp", "V0", "X"), ("sq", 1), ("cp", "V1", "X"), ("sq", 1), ("mul", "V1"), ("mul", "V0")]   # x^7 = x^4 x^2 x
+
+
+def emit_program(name, prog, doc):
+    g0, g1 = regs(0), regs(1)
+    lines = ["// %s" % doc, "SSA_DEV void %s(u64 &x, u64 &y) {" % name,
+             "    u32 x0 = lo32(x), x1 = hi32(x), y0 = lo32(y), y1 = hi32(y);", "    asm volatile("]
+    body = ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
+            "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
+    for g in (g0, g1):
+        body += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1)]
+    n_loop = 0
+    counts = {"valu": 0, "nop": 0}
+    sq_body = schedule([square(0), square(1)])
+    for op in prog:
+        if op[0] == "sq":
+            n = op[1]
+            if n <= 2:
+                seg = sq_body * n
+                body += seg
+            else:
+                lab = "L_%s_%%=_%d" % (name, n_loop)
+                n_loop += 1
+                body += ["s_mov_b32 s26, %d" % n, lab + ":"] + sq_body + ["s_sub_u32 s26, s26, 1", "s_cmp_lg_u32 s26, 0",
+                                                                          "s_cbranch_scc1 " + lab]
+            counts["valu"] += n * sum(1 for ln in sq_body if ln.startswith("v_"))
+            counts["nop"] += n * sum(1 for ln in sq_body if ln.startswith("s_nop"))
+        else:
+            if op[0] == "mul":
+                seg = schedule([multiply(0, op[1]), multiply(1, op[1])])
+            else:
+                seg = schedule([copy(0, op[1], op[2]), copy(1, op[1], op[2])])
+            body += seg
+            counts["valu"] += sum(1 for ln in seg if ln.startswith("v_"))
+            counts["nop"] += sum(1 for ln in seg if ln.startswith("s_nop"))
+    body += ["v_mov_b32 %%[x0], v%d" % g0["X"], "v_mov_b32 %%[x1], v%d" % (g0["X"] + 1),
+             "v_mov_b32 %%[y0], v%d" % g1["X"], "v_mov_b32 %%[y1], v%d" % (g1["X"] + 1)]
+    for i, ln in enumerate(body):
+        lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(body) else ""))
+    lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1)')
+    lines.append("        :")
+    clob = ['"v%d"' % r for r in range(BASE, BASE + 4 * N_PAIRS)] + ['"s%d"' % r for r in range(20, 27)] + ['"scc"', '"vcc"']
+    lines.append("        : " + ", ".join(clob) + ");")
+    lines += ["    x = mk64(x0, x1);", "    y = mk64(y0, y1);", "}"]
+    print("%s: %d VALU instructions + %d s_nop for the two values" % (name, counts["valu"], counts["nop"]))
+    return lines
 
 
 def _regs_of(text):
@@ -171,6 +263,9 @@ def main():
     lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1)')
     lines.append('        : [n] "s"(n)')
     used = sorted(set(range(BASE, BASE + 4 * 9)))
+    progs = emit_program("inv_sbox2_asm", INV_SBOX, "x <- x^(1/7), y <- y^(1/7): the whole 63-squaring / 9-product chain of "
+                         "both values in one block") + [""] + \
+        emit_program("sbox2_asm", SBOX, "x <- x^7, y <- y^7")
     clob = ['"v%d"' % r for r in used] + ['"s20"', '"s21"', '"s22"', '"s23"', '"s24"', '"s25"', '"s26"', '"scc"', '"vcc"']
     lines.append("        : " + ", ".join(clob) + ");")
     lines.append("    x = mk64(x0, x1);")
@@ -179,7 +274,7 @@ def main():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc",
                         "fp_chain_asm.inc")
     with open(path, "w") as fh:
-        fh.write("\n".join(lines) + "\n")
+        fh.write("\n".join(lines + [""] + progs) + "\n")
     print("wrote %s: %d VALU + %d s_nop per pair of squarings" % (path, n_valu, n_nop))
 
 
