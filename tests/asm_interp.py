@@ -1,0 +1,160 @@
+"""A one-lane interpreter for the subset of gfx950 VALU/SALU instructions the generated asm blocks use
+(schnorr-sig_amd/csrc/fp6_asm.inc, fp_chain_asm.inc).  Test infrastructure: lets the CPU suite execute the very
+instruction strings the GPU runs.  Besides the arithmetic it checks the two things hand-written gfx950 asm gets
+wrong silently:
+  * a VALU write of an SGPR pair / VCC needs two other instructions before a VALU reads it as carry-in or mask
+    (software-managed hazard: no interlock) -- `min_gap`;
+  * a v_mad_u64_u32 whose carry-out goes to the "dummy" pair must not overflow.
+"""
+import re
+
+M32, M64 = 0xFFFFFFFF, (1 << 64) - 1
+
+
+def extract_blocks(path):
+    """{function name: (asm lines, output names, {input name: (half, array, index) or C expression})} for every
+    SSA_DEV function of the generated file that contains an asm statement"""
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r"SSA_DEV void (\w+)\(.*?\) \{\n(.*?)\n\}\n", txt, re.S):
+        name, body = m.group(1), m.group(2)
+        am = re.search(r"asm(?: volatile)?\(\n(.*?)\n        : (.*?)\n        :(.*?)\n        : \"", body, re.S)
+        if not am:
+            continue
+        lines = [ln.strip().strip('"').replace("\\n\\t", "") for ln in am.group(1).split("\n") if ln.strip()]
+        outs = re.findall(r"\[(\w+)\] \"[=+]v\"", am.group(2))
+        ins = {}
+        for nm, half, arr, idx in re.findall(r"\[(\w+)\] \"v\"\((lo32|hi32)\((\w+)\[(\d+)\]\)\)", am.group(3)):
+            ins[nm] = (half, arr, int(idx))
+        out[name] = (lines, outs, ins)
+    return out
+
+
+class Lane:
+    def __init__(self, env, dummy_pairs=(), min_gap=3):
+        self.v = [0] * 256
+        self.s = {}
+        self.env = dict(env)
+        self.dummy = set(dummy_pairs)
+        self.min_gap = min_gap
+        self.issued = 0
+        self.written_at = {}
+        self.salu32 = {}
+
+    # ---- operands
+    def rv(self, o):
+        o = o.strip()
+        if o in self.env:
+            return self.env[o]
+        m = re.match(r"v\[(\d+):(\d+)\]$", o)
+        if m:
+            a = int(m.group(1))
+            return self.v[a] | (self.v[a + 1] << 32)
+        m = re.match(r"v(\d+)$", o)
+        if m:
+            return self.v[int(m.group(1))]
+        m = re.match(r"s\[(\d+):(\d+)\]$", o)
+        if m:      # an SGPR pair as a 64-bit DATA operand (set by s_mov_b32)
+            a = int(m.group(1))
+            return self.salu32.get(a, 0) | (self.salu32.get(a + 1, 0) << 32)
+        v = int(o, 0)
+        return v & M32 if v < 0 else v
+
+    def wv(self, o, val):
+        o = o.strip()
+        if o in self.env or o.startswith("%["):
+            self.env[o] = val & M32
+            return
+        m = re.match(r"v\[(\d+):(\d+)\]$", o)
+        if m:
+            a = int(m.group(1))
+            self.v[a], self.v[a + 1] = val & M32, (val >> 32) & M32
+            return
+        self.v[int(re.match(r"v(\d+)$", o).group(1))] = val & M32
+
+    def _key(self, o):
+        o = o.strip()
+        return "vcc" if o == "vcc" else int(re.match(r"s\[(\d+):(\d+)\]$", o).group(1))
+
+    def wc(self, o, bit):
+        k = self._key(o)
+        self.s[k] = bit
+        self.written_at[k] = self.issued
+
+    def rc(self, o):
+        k = self._key(o)
+        gap = self.issued - self.written_at.get(k, -100)
+        assert gap >= self.min_gap, "carry %s read %d slot(s) after its VALU write" % (o, gap)
+        return self.s.get(k, 0)
+
+    # ---- execution
+    def run(self, lines):
+        labels = {ln[:-1]: i for i, ln in enumerate(lines) if ln.endswith(":")}
+        pc, scc = 0, 0
+        while pc < len(lines):
+            ln = lines[pc]
+            pc += 1
+            if ln.endswith(":"):
+                continue
+            self.issued += 1
+            if ln.startswith("s_nop"):
+                continue
+            op, rest = ln.split(None, 1)
+            op = op.replace("_e64", "").replace("_e32", "")
+            a = [t.strip() for t in rest.split(",")]
+            if op == "v_mov_b32":
+                self.wv(a[0], self.rv(a[1]))
+            elif op == "v_not_b32":
+                self.wv(a[0], ~self.rv(a[1]) & M32)
+            elif op == "s_mov_b32":
+                self.salu32[int(a[0][1:])] = self.rv(a[1]) & M32
+            elif op == "s_sub_u32":
+                k = int(a[0][1:])
+                self.salu32[k] = (self.salu32[k] - self.rv(a[2])) & M32
+            elif op == "s_cmp_lg_u32":
+                scc = self.salu32[int(a[0][1:])] != self.rv(a[1])
+            elif op == "s_cbranch_scc1":
+                if scc:
+                    pc = labels[a[0]]
+            elif op == "v_mad_u64_u32":
+                r = self.rv(a[2]) * self.rv(a[3]) + self.rv(a[4])
+                if a[1].strip() in self.dummy:
+                    assert r <= M64, "a multiply-add with a discarded carry-out overflowed: " + ln
+                else:
+                    self.wc(a[1], r >> 64)
+                self.wv(a[0], r & M64)
+            elif op == "v_lshrrev_b32":
+                self.wv(a[0], self.rv(a[2]) >> int(a[1]))
+            elif op == "v_and_b32":
+                self.wv(a[0], self.rv(a[1]) & self.rv(a[2]))
+            elif op == "v_lshrrev_b64":
+                self.wv(a[0], self.rv(a[2]) >> int(a[1]))
+            elif op == "v_lshl_or_b32":
+                self.wv(a[0], ((self.rv(a[1]) << int(a[2])) & M32) | self.rv(a[3]))
+            elif op == "v_lshl_add_u64":
+                self.wv(a[0], ((self.rv(a[1]) << int(a[2])) + self.rv(a[3])) & M64)
+            elif op == "v_add_co_u32":
+                t = self.rv(a[2]) + self.rv(a[3])
+                self.wc(a[1], t >> 32)
+                self.wv(a[0], t & M32)
+            elif op == "v_addc_co_u32":
+                t = self.rv(a[2]) + self.rv(a[3]) + self.rc(a[4])
+                self.wc(a[1], t >> 32)
+                self.wv(a[0], t & M32)
+            elif op == "v_sub_co_u32":
+                d = self.rv(a[2]) - self.rv(a[3])
+                self.wc(a[1], 1 if d < 0 else 0)
+                self.wv(a[0], d & M32)
+            elif op == "v_subb_co_u32":
+                d = self.rv(a[2]) - self.rv(a[3]) - self.rc(a[4])
+                self.wc(a[1], 1 if d < 0 else 0)
+                self.wv(a[0], d & M32)
+            elif op == "v_subbrev_co_u32":
+                d = self.rv(a[3]) - self.rv(a[2]) - self.rc(a[4])
+                self.wc(a[1], 1 if d < 0 else 0)
+                self.wv(a[0], d & M32)
+            elif op == "v_cndmask_b32":
+                self.wv(a[0], self.rv(a[2]) if self.rc(a[3]) else self.rv(a[1]))
+            else:
+                raise AssertionError("unknown instruction: " + ln)
+        return self.env

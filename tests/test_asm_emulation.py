@@ -13,114 +13,23 @@ INC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
                    "fp_chain_asm.inc")
 
 
-def run(txt, fn, x, y, extra=""):
-    m = re.search(r"SSA_DEV void %s\(u64 &x, u64 &y%s\) \{.*?asm volatile\((.*?)\n        : \[x0\]" % (fn, extra), txt, re.S)
-    lines = [ln.strip().strip('"').replace("\\n\\t", "") for ln in m.group(1).split("\n") if ln.strip()]
-    v, sg = [0] * 256, {}
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import asm_interp as ai
+
+F6_INC = os.path.join(os.path.dirname(INC), "fp6_asm.inc")
+
+
+def run(txt_blocks, fn, x, y):
+    lines, outs, _ = txt_blocks[fn]
     env = {"%[x0]": x & M32, "%[x1]": x >> 32, "%[y0]": y & M32, "%[y1]": y >> 32, "%[n]": 5}
-
-    def rv(o):
-        o = o.strip()
-        if o in env:
-            return env[o]
-        mm = re.match(r"v\[(\d+):(\d+)\]$", o)
-        if mm:
-            a = int(mm.group(1))
-            return v[a] | (v[a + 1] << 32)
-        mm = re.match(r"v(\d+)$", o)
-        if mm:
-            return v[int(mm.group(1))]
-        mm = re.match(r"s\[(\d+):(\d+)\]$", o)
-        if mm:
-            return sg.get(int(mm.group(1)), 0)
-        return M32 if o == "-1" else int(o)
-
-    def wv(o, val):
-        o = o.strip()
-        if o in env:
-            env[o] = val & M32
-            return
-        mm = re.match(r"v\[(\d+):(\d+)\]$", o)
-        if mm:
-            a = int(mm.group(1))
-            v[a], v[a + 1] = val & M32, (val >> 32) & M32
-            return
-        v[int(re.match(r"v(\d+)$", o).group(1))] = val & M32
-
-    labels = {ln[:-1]: i for i, ln in enumerate(lines) if ln.endswith(":")}
-    pc, s26, scc, issued = 0, 0, 0, 0
-    sg_written_at = {}
-
-    def ws(o, val):
-        k = int(re.match(r"s\[(\d+):(\d+)\]$", o.strip()).group(1))
-        sg[k] = val
-        sg_written_at[k] = issued
-
-    def rs(o):
-        k = int(re.match(r"s\[(\d+):(\d+)\]$", o.strip()).group(1))
-        assert issued - sg_written_at.get(k, -10) >= 3, "SGPR pair %d read %d slots after its VALU write" % (k, issued - sg_written_at[k])
-        return sg.get(k, 0)
-
-    while pc < len(lines):
-        ln = lines[pc]
-        pc += 1
-        if ln.endswith(":"):
-            continue
-        issued += 1
-        if ln.startswith("s_nop"):
-            continue
-        op, rest = ln.split(None, 1)
-        a = [t.strip() for t in rest.split(",")]
-        if op == "v_mov_b32":
-            wv(a[0], rv(a[1]))
-        elif op == "s_mov_b32":
-            s26 = rv(a[1])
-        elif op == "s_sub_u32":
-            s26 -= 1
-        elif op == "s_cmp_lg_u32":
-            scc = s26 != 0
-        elif op == "s_cbranch_scc1":
-            if scc:
-                pc = labels[a[0]]
-        elif op == "v_mad_u64_u32":
-            r = rv(a[2]) * rv(a[3]) + rv(a[4])
-            assert a[1] == "s[24:25]" and r <= M64, "a multiply-add with a discarded carry-out overflowed"
-            wv(a[0], r)
-        elif op == "v_lshrrev_b32":
-            wv(a[0], rv(a[2]) >> int(a[1]))
-        elif op == "v_and_b32":
-            wv(a[0], rv(a[1]) & rv(a[2]))
-        elif op == "v_lshrrev_b64":
-            wv(a[0], rv(a[2]) >> int(a[1]))
-        elif op == "v_lshl_or_b32":
-            wv(a[0], ((rv(a[1]) << int(a[2])) & M32) | rv(a[3]))
-        elif op == "v_sub_co_u32":
-            d = rv(a[2]) - rv(a[3])
-            ws(a[1], 1 if d < 0 else 0)
-            wv(a[0], d & M32)
-        elif op == "v_subbrev_co_u32":
-            d = rv(a[3]) - rv(a[2]) - rs(a[4])
-            ws(a[1], 1 if d < 0 else 0)
-            wv(a[0], d & M32)
-        elif op == "v_cndmask_b32":
-            wv(a[0], rv(a[2]) if rs(a[3]) else rv(a[1]))
-        elif op == "v_lshl_add_u64":
-            wv(a[0], ((rv(a[1]) << int(a[2])) + rv(a[3])) & M64)
-        elif op == "v_add_co_u32":
-            t = rv(a[2]) + rv(a[3])
-            ws(a[1], t >> 32)
-            wv(a[0], t & M32)
-        elif op == "v_addc_co_u32":
-            t = rv(a[2]) + rv(a[3]) + rs(a[4])
-            ws(a[1], t >> 32)
-            wv(a[0], t & M32)
-        else:
-            raise AssertionError("unknown instruction: " + ln)
-    return env["%[x0]"] | (env["%[x1]"] << 32), env["%[y0]"] | (env["%[y1]"] << 32)
+    lane = ai.Lane(env, dummy_pairs=("s[24:25]",))
+    e = lane.run(lines)
+    return e["%[x0]"] | (e["%[x1]"] << 32), e["%[y0]"] | (e["%[y1]"] << 32)
 
 
 def test_generated_sbox_asm_on_the_cpu():
-    txt = open(INC).read()
+    txt = ai.extract_blocks(INC)
     rnd = random.Random(5)
     e_inv = 10540996611094048183          # 7^-1 mod (p - 1)
     vals = [0, 1, P - 1, P, P + 1, 2**64 - 1, 2**32, 2**32 - 1, 2**63, 2**64 - 2**32] + [rnd.randrange(2**64) for _ in range(30)]
@@ -130,8 +39,72 @@ def test_generated_sbox_asm_on_the_cpu():
         assert rx % P == pow(a, e_inv, P) and ry % P == pow(b, e_inv, P), (hex(a), hex(b))
         rx, ry = run(txt, "sbox2_asm", a, b)
         assert rx % P == pow(a, 7, P) and ry % P == pow(b, 7, P), (hex(a), hex(b))
-        rx, ry = run(txt, "fp_sqr2_n_asm", a, b, extra=", int n")     # n = 5 in the interpreter
+        rx, ry = run(txt, "fp_sqr2_n_asm", a, b)     # n = 5 in the interpreter
         assert rx % P == pow(a, 32, P) and ry % P == pow(b, 32, P)
+
+
+def _f6_mulmod(u, v):
+    t = [0] * 12
+    for i, x in enumerate(u):
+        for j, y in enumerate(v):
+            t[i + j] += x * y
+    return [(t[k] + 7 * t[k + 6]) % P for k in range(6)]
+
+
+def test_generated_fp6_blocks_on_the_cpu():
+    """every block of fp6_asm.inc (plain product / square and the fused product + linear-term blocks) through the
+    interpreter, loose and edge operands, against plain integers; carry wait states checked on the way"""
+    blocks = ai.extract_blocks(F6_INC)
+    assert len(blocks) == 9
+    rnd = random.Random(11)
+    edge = [0, 1, P - 1, P, 2**64 - 1, 2**32 - 1, 2**32, 2**64 - 2**32]
+
+    def elem(kind):
+        if kind == "edge":
+            return [rnd.choice(edge) for _ in range(6)]
+        if kind == "max":
+            return [2**64 - 1] * 6
+        if kind == "zero":
+            return [0] * 6
+        return [rnd.randrange(2**64) for _ in range(6)]
+
+    spec = {   # name -> (is square, second product, linear terms [(sign, c, operand)])
+        "f6_mul_core_asm": (False, False, []),
+        "f6_sqr_core_asm": (True, False, []),
+        "f6_sqr_sub2_core_asm": (True, False, [(-1, 1, "x"), (-1, 1, "y")]),
+        "f6_sqr_add3x_core_asm": (True, False, [(1, 3, "x")]),
+        "f6_sqr_sub4x_core_asm": (True, False, [(-1, 4, "x")]),
+        "f6_mul_sub8x_core_asm": (False, False, [(-1, 8, "x")]),
+        "f6_mul_subx_core_asm": (False, False, [(-1, 1, "x")]),
+        "f6_mul2_add_core_asm": (False, True, []),
+        "f6_sqr_subx_sub2y_core_asm": (True, False, [(-1, 1, "x"), (-1, 2, "y")]),
+    }
+    kinds = ["rand"] * 6 + ["edge"] * 4 + ["max", "zero"]
+    for name, (is_sqr, two, terms) in spec.items():
+        lines, outs, ins = blocks[name]
+        for kind in kinds:
+            arr = {"a": elem(kind), "b": elem("rand" if kind == "zero" else kind), "c": elem(kind), "d": elem("rand"),
+                   "x": elem(kind), "y": elem("edge" if kind == "rand" else kind)}
+            # the pre-scaled operands the C++ wrappers hand over (any representative mod p is allowed: canonical here)
+            arr["b7"] = [7 * t % P for t in arr["b"]]
+            arr["d7"] = [7 * t % P for t in arr["d"]]
+            arr["a2"] = [2 * t % P for t in arr["a"]]
+            arr["a7"] = [7 * t % P for t in arr["a"]]
+            arr["a14"] = [14 * t % P for t in arr["a"]]
+            env = {}
+            for nm, (half, an, idx) in ins.items():
+                val = arr[an][idx]
+                env["%%[%s]" % nm] = val & M32 if half == "lo32" else val >> 32
+            lane = ai.Lane(env, dummy_pairs=())
+            # the opening multiplies write their (impossible) carry to s[0:1] and nobody reads it before it is rewritten
+            e = lane.run(lines)
+            got = [(e["%%[r%dl]" % k] | (e["%%[r%dh]" % k] << 32)) % P for k in range(6)]
+            want = _f6_mulmod(arr["a"], arr["a"] if is_sqr else arr["b"])
+            if two:
+                want = [(w + z) % P for w, z in zip(want, _f6_mulmod(arr["c"], arr["d"]))]
+            for sign, c, an in terms:
+                want = [(w + sign * c * t) % P for w, t in zip(want, arr[an])]
+            assert got == want, (name, kind)
 
 
 def test_generated_file_is_up_to_date():

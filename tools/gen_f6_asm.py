@@ -88,19 +88,26 @@ def init2(acc, x, y, z, w, bias=None):
     ]
 
 
+S2 = "s[4:5]"      # free during the accumulation (the reductions use s[0:11])
+
+
 def mac(acc, x, y):
+    """acc += x*y: the four multiplies first (c1's two separated by one instruction), then the four carry adds --
+    every carry is consumed four slots after it was produced (two wait states are required between a VALU write of
+    an SGPR pair or VCC and the VALU read of it; round 1's order read VCC after ONE intervening multiply, which the
+    hardware tolerated but the rule does not allow -- tests/test_asm_emulation.py enforces the rule now)"""
     xl, xh, yl, yh = "%%[%sl]" % x, "%%[%sh]" % x, "%%[%sl]" % y, "%%[%sh]" % y
     c0, c1, c2 = acc.pair(0), acc.pair(1), acc.pair(2)
     k0, k1, k2 = acc.kk(0), acc.kk(1), acc.kk(2)
     return [
-        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c0, S0, xl, yl, c0),
         "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (c1, xl, yh, c1),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c0, S0, xl, yl, c0),
+        "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c1, S2, xh, yl, c1),
         "v_mad_u64_u32 %s, %s, %s, %s, %s" % (c2, S1, xh, yh, c2),
         "v_addc_co_u32 %s, vcc, 0, %s, vcc" % (k1, k1),
-        "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (c1, xh, yl, c1),
         "v_addc_co_u32 %s, %s, 0, %s, %s" % (k0, S0, k0, S0),
+        "v_addc_co_u32 %s, %s, 0, %s, %s" % (k1, S2, k1, S2),
         "v_addc_co_u32 %s, %s, 0, %s, %s" % (k2, S1, k2, S1),
-        "v_addc_co_u32 %s, vcc, 0, %s, vcc" % (k1, k1),
     ]
 
 
