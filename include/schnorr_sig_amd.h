@@ -213,8 +213,15 @@ int ssa_ctx_sync(ssa_ctx *ctx);
  * SSA_FLAG_CHECK_TORSION; an index >= m gives SSA_MALFORMED).  A key set belongs to the context it was created
  * on; destroy it before the context. */
 typedef struct ssa_keyset ssa_keyset;
-int ssa_keyset_create(ssa_ctx *ctx, const uint8_t *pks, const uint8_t *pk_inf, size_t m, ssa_keyset **out);
-int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t m,
+/* table kind: SSA_KEYSET_LADDER keeps eight multiples per key (2 KB; verification runs the 252-doubling ladder),
+ * SSA_KEYSET_COMB a comb of [d * 2^(8w)]P, w < 32, d < 256 per key (768 KB; [h]P becomes 32 mixed additions, no
+ * doublings -- about 5x less curve work per signature), SSA_KEYSET_AUTO the comb while all tables fit 4 GB */
+#define SSA_KEYSET_AUTO 0u
+#define SSA_KEYSET_COMB 1u
+#define SSA_KEYSET_LADDER 2u
+int ssa_keyset_create(ssa_ctx *ctx, const uint8_t *pks, const uint8_t *pk_inf, size_t m, uint32_t flags,
+                      ssa_keyset **out);
+int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t m, uint32_t flags,
                              ssa_keyset **out);
 void ssa_keyset_destroy(ssa_keyset *ks);
 /* per-key status (m bytes): 0 usable, 1 not in the prime subgroup, 3 malformed */

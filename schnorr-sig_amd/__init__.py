@@ -38,6 +38,7 @@ FLAG_CHECK_TORSION = 1
 FLAG_FORCE_LANE = 2   # throughput kernels (one signature per lane) whatever the batch size
 FLAG_FORCE_COOP = 4   # low-latency kernel (one wave per signature) whatever the batch size
 FLAG_SIG_FLAG_BYTE = 8  # verify_batch's semantics for byte 48 of the signature (src/batch.rs:104)
+KEYSET_KINDS = {"auto": 0, "comb": 1, "ladder": 2}
 _MODE_FLAGS = {None: 0, "auto": 0, "lane": FLAG_FORCE_LANE, "coop": FLAG_FORCE_COOP}
 
 Q = 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
@@ -94,8 +95,8 @@ def _load():
         "ssa_verify_batch_msm": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp]),
         "ssa_verify_batch_msm_device": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp, u32, vp]),
         "ssa_verify_keyed_many": (i32, [vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
-        "ssa_keyset_create": (i32, [vp, vp, vp, sz, C.POINTER(vp)]),
-        "ssa_keyset_create_device": (i32, [vp, vp, vp, sz, C.POINTER(vp)]),
+        "ssa_keyset_create": (i32, [vp, vp, vp, sz, u32, C.POINTER(vp)]),
+        "ssa_keyset_create_device": (i32, [vp, vp, vp, sz, u32, C.POINTER(vp)]),
         "ssa_keyset_destroy": (None, [vp]),
         "ssa_keyset_status": (i32, [vp, vp]),
         "ssa_verify_many_indexed": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, u64p]),
@@ -304,17 +305,19 @@ class Engine:
         return pks, inf, st
 
     # ---- keyed context (many signatures by few signers) ---------------------------------
-    def keyset_create(self, pks, pk_inf=None):
-        """-> opaque key set handle: subgroup check and ladder tables done once per key"""
+    def keyset_create(self, pks, pk_inf=None, kind="auto"):
+        """-> opaque key set handle: subgroup check and tables done once per key.  kind: "auto", "comb" (768 KB
+        per key, no doublings at verification time) or "ladder" (2 KB per key)"""
         pks = _np_u8(pks, 96)
         inf = _np_u8(pk_inf) if pk_inf is not None else None
         ks = C.c_void_p()
-        _check(_lib.ssa_keyset_create(self._ctx, _ptr(pks), _ptr(inf), pks.shape[0], C.byref(ks)), "ssa_keyset_create")
+        _check(_lib.ssa_keyset_create(self._ctx, _ptr(pks), _ptr(inf), pks.shape[0], KEYSET_KINDS[kind], C.byref(ks)),
+               "ssa_keyset_create")
         return ks
 
-    def keyset_create_device(self, d_pks, m, d_pk_inf=0):
+    def keyset_create_device(self, d_pks, m, d_pk_inf=0, kind="auto"):
         ks = C.c_void_p()
-        _check(_lib.ssa_keyset_create_device(self._ctx, d_pks, d_pk_inf or None, m, C.byref(ks)),
+        _check(_lib.ssa_keyset_create_device(self._ctx, d_pks, d_pk_inf or None, m, KEYSET_KINDS[kind], C.byref(ks)),
                "ssa_keyset_create_device")
         return ks
 

@@ -607,12 +607,13 @@ extern "C" int ssa_verify_keyed_many(ssa_ctx *ctx, const uint8_t *keyed, const u
 struct ssa_keyset {
     ssa_ctx *ctx = nullptr;
     size_t m = 0;
-    DevBuf tab, status, pks;
+    bool comb = false;      // per-key comb tables (768 KB per key) instead of the ladder's eight multiples
+    DevBuf tab, status, pks, ktab;
 };
 
 extern "C" int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t m,
-                                        ssa_keyset **out) {
-    if (!ctx || !out || !d_pks || m == 0 || m > 0xffffffffull) return SSA_ERR_ARG;
+                                        uint32_t flags, ssa_keyset **out) {
+    if (!ctx || !out || !d_pks || m == 0 || m > 0xffffffffull || flags > SSA_KEYSET_LADDER) return SSA_ERR_ARG;
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     ssa_keyset *ks = new ssa_keyset();
@@ -636,18 +637,37 @@ extern "C" int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, cons
         ssa_keyset_destroy(ks);
         return rc ? rc : SSA_ERR_HIP;
     }
+    // few keys: a comb table per key (no doublings at verification time); many keys: the ladder tables only
+    const size_t comb_bytes = m * KTAB_ENTRIES_PER_KEY * 12 * sizeof(u64);
+    ks->comb = flags == SSA_KEYSET_COMB || (flags == SSA_KEYSET_AUTO && comb_bytes <= ((size_t)4 << 30));
+    if (ks->comb) {
+        if (ks->ktab.reserve(comb_bytes)) {
+            ssa_keyset_destroy(ks);
+            return SSA_ERR_HIP;
+        }
+        rc = timed_launch(ctx, "ssa_k_keycomb_build", [&] {
+            hipLaunchKernelGGL(ssa_k_keycomb_build, dim3(grid_for(m * KTAB_ENTRIES_PER_KEY, 256)), dim3(256), 0,
+                               ctx->stream, (const u8 *)ks->pks.p, d_pk_inf, (const u8 *)ks->status.p, m,
+                               (u64 *)ks->ktab.p);
+        });
+        if (rc != 0 || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            ssa_keyset_destroy(ks);
+            return rc ? rc : SSA_ERR_HIP;
+        }
+    }
     *out = ks;
     return 0;
 }
 
-extern "C" int ssa_keyset_create(ssa_ctx *ctx, const uint8_t *pks, const uint8_t *pk_inf, size_t m, ssa_keyset **out) {
+extern "C" int ssa_keyset_create(ssa_ctx *ctx, const uint8_t *pks, const uint8_t *pk_inf, size_t m, uint32_t flags,
+                                 ssa_keyset **out) {
     if (!ctx || !out || !pks || m == 0) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const void *p_pks, *p_inf = nullptr;
     if (int rc = stage_up(ctx, ctx->st_pks, pks, m * 96, &p_pks)) return rc;
     if (pk_inf)
         if (int rc = stage_up(ctx, ctx->st_inf, pk_inf, m, &p_inf)) return rc;
-    return ssa_keyset_create_device(ctx, (const u8 *)p_pks, (const u8 *)p_inf, m, out);
+    return ssa_keyset_create_device(ctx, (const u8 *)p_pks, (const u8 *)p_inf, m, flags, out);
 }
 
 extern "C" void ssa_keyset_destroy(ssa_keyset *ks) {
@@ -659,6 +679,7 @@ extern "C" void ssa_keyset_destroy(ssa_keyset *ks) {
     ks->tab.release();
     ks->status.release();
     ks->pks.release();
+    ks->ktab.release();
     delete ks;
 }
 
@@ -688,6 +709,12 @@ extern "C" int ssa_verify_many_indexed_device(ssa_ctx *ctx, ssa_keyset *ks, cons
                            (const u8 *)ks->pks.p, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr, d_key_idx, (u32)ks->m);
     });
     if (rc) return rc;
+    if (ks->comb)
+        return timed_launch(ctx, "ssa_k_verify_keyed", [&] {
+            hipLaunchKernelGGL(ssa_k_verify_keyed_comb, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_sigs,
+                               d_key_idx, (const u64 *)ks->ktab.p, (const u8 *)ks->status.p, (u32)ks->m,
+                               (const u64 *)ctx->ws_h.p, (const u64 *)ctx->d_gtab, n, flags, d_status_out, d_fail);
+        });
     return timed_launch(ctx, "ssa_k_verify_keyed", [&] {
         hipLaunchKernelGGL(ssa_k_verify_keyed, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_sigs, d_key_idx,
                            (const u64 *)ks->tab.p, (const u8 *)ks->status.p, (u32)ks->m, (const u64 *)ctx->ws_h.p,

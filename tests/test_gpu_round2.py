@@ -197,9 +197,11 @@ def test_multi_device_msm_verdict_equals_single_context(engine, oracle, n):
 
 
 # ---------------------------------------------------------------- keyed context
-def test_keyed_context_64_keys_65536_signatures(engine, oracle):
+@pytest.mark.parametrize("kind", ["ladder", "comb"])
+def test_keyed_context_64_keys_65536_signatures(engine, oracle, kind):
     """m = 64 keys x 2^16 signatures through ssa_keyset_create + ssa_verify_many_indexed, every lane against the
-    oracle's Signature::verify; keys that fail their checks, an out-of-range index."""
+    oracle's Signature::verify; keys that fail their checks, an out-of-range index.  Both table kinds: the eight
+    multiples of the ladder and the per-key comb (no doublings)."""
     rng = np.random.default_rng(700)
     m, n = 64, 1 << 16
     key_sks = make_scalars(rng, m)
@@ -222,7 +224,7 @@ def test_keyed_context_64_keys_65536_signatures(engine, oracle):
     keys[62, 8:16] = 0xFF
     keys[63] = 0
     inf[63] = 1
-    ks = engine.keyset_create(keys, pk_inf=inf)
+    ks = engine.keyset_create(keys, pk_inf=inf, kind=kind)
     try:
         assert list(engine.keyset_status(ks, m)[60:]) == [1, 3, 3, 0]
         assert (engine.keyset_status(ks, m)[:60] == 0).all()
