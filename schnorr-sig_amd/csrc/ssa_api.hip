@@ -228,6 +228,16 @@ extern "C" int ssa_rescue_hash_many_device(ssa_ctx *ctx, const uint64_t *d_felts
     });
 }
 
+// one chunk of challenge hashes on `hs` (the shared upload pipeline of the host-buffer entry points)
+int ssa_internal_hash_chunk(ssa_ctx *ctx, hipStream_t hs, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
+                            const uint64_t *d_off, size_t msg_stride, size_t msg_len, size_t cnt, uint64_t *d_h) {
+    MsgView mv{d_msgs, d_off, msg_stride, msg_len};
+    hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(cnt, 256)), dim3(256), 0, hs, ctx->d_params, d_sigs, d_pks, mv, cnt,
+                       (u64 *)d_h, (u8 *)nullptr, (const u32 *)nullptr, 0u);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
                               const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n) {
     if (ctx->ws_h.reserve(n * 4 * sizeof(u64))) return SSA_ERR_HIP;
@@ -313,86 +323,26 @@ extern "C" int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compres
 }
 
 // ------------------------------------------------------------------ host entry points
-// Caller memory pinned in place for the duration of one call (hipHostRegister): the DMA engines then read it
-// directly and asynchronously -- an upload from pageable memory is staged by the runtime and does not overlap the
-// kernels (measured: DESIGN.md).  Never kept across calls: the caller may free or remap the range.
-struct PinnedRange {
-    void *p = nullptr;
-    bool on = false;
-    bool pin(const void *ptr, size_t bytes) {
-        if (!ptr || bytes == 0) return true;
-        if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        p = const_cast<void *>(ptr);
-        on = true;
-        return true;
-    }
-    ~PinnedRange() {
-        if (on) (void)hipHostUnregister(p);
-    }
-};
-
-// Large host-buffer batch: uploads in chunks on the copy stream, the challenge hashes of chunk c start as soon as
-// chunk c has arrived (they are 27 % of the work) -- alternating between two streams, because a lane hashes for
-// ~4 ms and a launch's tail would otherwise idle most of the chip once per chunk -- and one verification launch
-// over the whole batch at the end: the ladder kernel keeps its full-size grid, only the first chunk's upload is exposed.
+// Large host-buffer batch: the shared upload + hash pipeline (ssa_ctx.hpp: pipelined_upload_hash), then ONE
+// verification launch over the whole batch: the ladder kernel keeps its full-size grid, only the first chunk's
+// upload is exposed.
 static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                                  const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
                                  size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out, bool *used) {
+    PipelinedInputs pin;
+    PinnedRange r_status;
     *used = false;
-    const size_t mb = msgs_bytes(msg_off, msg_stride, msg_len, n);
-    PinnedRange r_sigs, r_pks, r_msgs, r_inf, r_off, r_status;
-    if (!r_sigs.pin(sigs, n * 81) || !r_pks.pin(pks, n * 96) || !r_msgs.pin(msgs, mb) || !r_inf.pin(pk_inf, n) ||
-        !r_off.pin(msg_off, msg_off ? (n + 1) * sizeof(uint64_t) : 0) || !r_status.pin(status_out, n))
-        return 0;   // cannot pin (e.g. a read-only mapping): the caller falls back to the plain path
-    *used = true;
-    if (ctx->st_sigs.reserve(n * 81) || ctx->st_pks.reserve(n * 96) || ctx->st_msgs.reserve(mb + 16) ||
-        ctx->st_status.reserve(n + 16) || ctx->ws_h.reserve(n * 4 * sizeof(u64)) ||
+    if (!r_status.pin(status_out, n)) return 0;
+    if (int rc = pipelined_upload_hash(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, pin, used)) return rc;
+    if (!*used) return 0;
+    if (ctx->st_status.reserve(n + 16) ||
         ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64)))
         return SSA_ERR_HIP;
-    const u8 *d_inf = nullptr;
-    const u64 *d_off = nullptr;
-    if (msg_off) {
-        for (size_t i = 0; i < n; i++)
-            if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > 0xffffffffull) return SSA_ERR_ARG;
-        if (ctx->st_off.reserve((n + 1) * sizeof(uint64_t))) return SSA_ERR_HIP;
-        HIP_TRY(hipMemcpyAsync(ctx->st_off.p, msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy_stream));
-        d_off = (const u64 *)ctx->st_off.p;
-    }
-    if (pk_inf) {
-        if (ctx->st_inf.reserve(n)) return SSA_ERR_HIP;
-        HIP_TRY(hipMemcpyAsync(ctx->st_inf.p, pk_inf, n, hipMemcpyHostToDevice, ctx->copy_stream));
-        d_inf = (const u8 *)ctx->st_inf.p;
-    }
     unsigned long long *d_fail = (unsigned long long *)ctx->ws_fail.p;
     HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), ctx->stream));
-    const unsigned chunks = ctx->pipeline_chunks;
-    u8 *d_sigs = (u8 *)ctx->st_sigs.p, *d_pks = (u8 *)ctx->st_pks.p, *d_msgs = (u8 *)ctx->st_msgs.p;
-    for (unsigned c = 0; c < chunks; c++) {
-        const size_t lo = n * c / chunks, hi = n * (c + 1) / chunks, cnt = hi - lo;
-        if (cnt == 0) continue;
-        HIP_TRY(hipMemcpyAsync(d_sigs + 81 * lo, sigs + 81 * lo, cnt * 81, hipMemcpyHostToDevice, ctx->copy_stream));
-        HIP_TRY(hipMemcpyAsync(d_pks + 96 * lo, pks + 96 * lo, cnt * 96, hipMemcpyHostToDevice, ctx->copy_stream));
-        const size_t m_lo = msg_off ? (size_t)msg_off[lo] : lo * msg_stride;
-        const size_t m_hi = msg_off ? (size_t)msg_off[hi] : (hi == n ? mb : hi * msg_stride);
-        if (m_hi > m_lo)
-            HIP_TRY(hipMemcpyAsync(d_msgs + m_lo, msgs + m_lo, m_hi - m_lo, hipMemcpyHostToDevice, ctx->copy_stream));
-        HIP_TRY(hipEventRecord(ctx->copy_done[c], ctx->copy_stream));
-        hipStream_t hs = ctx->hash_stream[c & 1u];
-        HIP_TRY(hipStreamWaitEvent(hs, ctx->copy_done[c], 0));
-        MsgView mv{msg_off ? d_msgs : d_msgs + lo * msg_stride, msg_off ? d_off + lo : nullptr, msg_stride, msg_len};
-        hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(cnt, 256)), dim3(256), 0, hs, ctx->d_params,
-                           (const u8 *)(d_sigs + 81 * lo), (const u8 *)(d_pks + 96 * lo), mv, cnt,
-                           (u64 *)ctx->ws_h.p + 4 * lo, (u8 *)nullptr, (const u32 *)nullptr, 0u);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ctx->hash_done[c], hs));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->hash_done[c], 0));
-    }
     int rc = timed_launch(ctx, "ssa_k_verify", [&] {
         hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(n, ctx->verify_block)), dim3(ctx->verify_block), 0, ctx->stream,
-                           (const u8 *)d_sigs, (const u8 *)d_pks, d_inf, (const u64 *)ctx->ws_h.p,
+                           pin.s.sigs, pin.s.pks, pin.s.inf, (const u64 *)ctx->ws_h.p,
                            (const u64 *)ctx->d_gtab, (u64 *)ctx->ws_tab.p, n, flags, (u8 *)ctx->st_status.p, d_fail);
     });
     if (rc) return rc;

@@ -155,6 +155,93 @@ static inline int stage_msgs(ssa_ctx *ctx, const uint8_t *msgs, const uint64_t *
 }
 
 
+// defined in ssa_api.hip
+int ssa_internal_hash_chunk(ssa_ctx *ctx, hipStream_t hs, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
+                            const uint64_t *d_off, size_t msg_stride, size_t msg_len, size_t cnt, uint64_t *d_h);
+
+// Caller memory pinned in place for the duration of one call (hipHostRegister): the DMA engines then read it
+// directly and asynchronously -- an upload from pageable memory is staged by the runtime and does not overlap the
+// kernels (measured: DESIGN.md).  Never kept across calls: the caller may free or remap the range.
+struct PinnedRange {
+    void *p = nullptr;
+    bool on = false;
+    bool pin(const void *ptr, size_t bytes) {
+        if (!ptr || bytes == 0) return true;
+        if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        p = const_cast<void *>(ptr);
+        on = true;
+        return true;
+    }
+    ~PinnedRange() {
+        if (on) (void)hipHostUnregister(p);
+    }
+};
+struct PipelinedInputs {
+    PinnedRange r_sigs, r_pks, r_msgs, r_inf, r_off;
+    StagedInputs s;     // device copies (context staging buffers)
+};
+
+// Uploads of a large host-buffer batch in chunks on the copy stream; the challenge hashes of chunk c start as soon as
+// chunk c has arrived (they are 27 % of the per-signature work, 62 % of the MSM form), alternating between two
+// streams -- a lane hashes for ~4 ms and a launch's tail would otherwise idle most of the chip once per chunk.
+// On return ctx->stream waits for all of it: whatever the caller enqueues next sees the inputs and ctx->ws_h.
+// *used == false: the ranges could not be pinned (e.g. a read-only mapping) and nothing was enqueued.
+static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                        const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                                        size_t n, PipelinedInputs &pin, bool *used) {
+    *used = false;
+    const size_t mb = msgs_bytes(msg_off, msg_stride, msg_len, n);
+    if (!pin.r_sigs.pin(sigs, n * 81) || !pin.r_pks.pin(pks, n * 96) || !pin.r_msgs.pin(msgs, mb) ||
+        !pin.r_inf.pin(pk_inf, n) || !pin.r_off.pin(msg_off, msg_off ? (n + 1) * sizeof(uint64_t) : 0))
+        return 0;
+    *used = true;
+    if (ctx->st_sigs.reserve(n * 81) || ctx->st_pks.reserve(n * 96) || ctx->st_msgs.reserve(mb + 16) ||
+        ctx->ws_h.reserve(n * 4 * sizeof(u64)))
+        return SSA_ERR_HIP;
+    const u64 *d_off = nullptr;
+    if (msg_off) {
+        for (size_t i = 0; i < n; i++)
+            if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > 0xffffffffull) return SSA_ERR_ARG;
+        if (ctx->st_off.reserve((n + 1) * sizeof(uint64_t))) return SSA_ERR_HIP;
+        HIP_TRY(hipMemcpyAsync(ctx->st_off.p, msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy_stream));
+        d_off = (const u64 *)ctx->st_off.p;
+    }
+    if (pk_inf) {
+        if (ctx->st_inf.reserve(n)) return SSA_ERR_HIP;
+        HIP_TRY(hipMemcpyAsync(ctx->st_inf.p, pk_inf, n, hipMemcpyHostToDevice, ctx->copy_stream));
+        pin.s.inf = (const u8 *)ctx->st_inf.p;
+    }
+    const unsigned chunks = ctx->pipeline_chunks;
+    u8 *d_sigs = (u8 *)ctx->st_sigs.p, *d_pks = (u8 *)ctx->st_pks.p, *d_msgs = (u8 *)ctx->st_msgs.p;
+    for (unsigned c = 0; c < chunks; c++) {
+        const size_t lo = n * c / chunks, hi = n * (c + 1) / chunks, cnt = hi - lo;
+        if (cnt == 0) continue;
+        HIP_TRY(hipMemcpyAsync(d_sigs + 81 * lo, sigs + 81 * lo, cnt * 81, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(hipMemcpyAsync(d_pks + 96 * lo, pks + 96 * lo, cnt * 96, hipMemcpyHostToDevice, ctx->copy_stream));
+        const size_t m_lo = msg_off ? (size_t)msg_off[lo] : lo * msg_stride;
+        const size_t m_hi = msg_off ? (size_t)msg_off[hi] : (hi == n ? mb : hi * msg_stride);
+        if (m_hi > m_lo)
+            HIP_TRY(hipMemcpyAsync(d_msgs + m_lo, msgs + m_lo, m_hi - m_lo, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(hipEventRecord(ctx->copy_done[c], ctx->copy_stream));
+        hipStream_t hs = ctx->hash_stream[c & 1u];
+        HIP_TRY(hipStreamWaitEvent(hs, ctx->copy_done[c], 0));
+        if (int rc = ssa_internal_hash_chunk(ctx, hs, d_sigs + 81 * lo, d_pks + 96 * lo,
+                                             msg_off ? d_msgs : d_msgs + lo * msg_stride, msg_off ? d_off + lo : nullptr,
+                                             msg_stride, msg_len, cnt, (uint64_t *)ctx->ws_h.p + 4 * lo))
+            return rc;
+        HIP_TRY(hipEventRecord(ctx->hash_done[c], hs));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->hash_done[c], 0));
+    }
+    pin.s.sigs = d_sigs;
+    pin.s.pks = d_pks;
+    pin.s.msgs = d_msgs;
+    pin.s.off = d_off;
+    return 0;
+}
+
 // defined in ssa_api.hip: hash_message + Scalar::from_bits_vartime for n signatures into ctx->ws_h
 int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
                               const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n);

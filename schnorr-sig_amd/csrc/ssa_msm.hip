@@ -450,7 +450,8 @@ extern "C" int ssa_debug_chacha20(ssa_ctx *ctx, const uint8_t key[32], const uin
 
 static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
                    const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
-                   const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out);
+                   const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out,
+                   bool hashed = false);
 
 extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
                                            const uint8_t *d_pk_inf, const uint8_t *d_msgs,
@@ -463,9 +464,11 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
 }
 
 // the kernels of one MSM-form batch on ctx->stream: a verdict (d_partial_out == nullptr) or this shard's partial sums
+// hashed: ctx->ws_h already holds the challenge scalars (the host-buffer pipeline computed them while uploading)
 static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
                    const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
-                   const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out) {
+                   const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out,
+                   bool hashed) {
     if (!ctx || (!d_verdict_out && !d_partial_out)) return SSA_ERR_ARG;
     if (n && (!d_sigs || !d_pks)) return SSA_ERR_ARG;
     if (d_coeffs && (coeff_bytes == 0 || coeff_bytes > 32)) return SSA_ERR_ARG;
@@ -516,7 +519,8 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
     HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->msm_bounds.p, 0, nb * 8, ctx->stream));
     // challenge scalars h_i with the kernel of the per-lane path
-    if (int rc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+    if (!hashed)
+        if (int rc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
     int rc = timed_launch(ctx, "msm_k_prepare", [&] {
         hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, ctx->stream, d_sigs, d_pks, d_pk_inf,
                            (const u64 *)ctx->ws_h.p, d_coeffs, coeff_bytes, n, (u64 *)ctx->msm_points.p,
@@ -639,6 +643,32 @@ extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uin
     HIP_TRY(hipSetDevice(ctx->device));
     // Scalar::random(rng) (src/batch.rs:75-78): caller-supplied 32-byte scalars, or (coeffs == NULL) 128-bit
     // coefficients drawn on the device from a ChaCha20 stream keyed with getrandom(2)
+    if (n >= ctx->pipeline_min_n && ctx->pipeline_chunks > 1) {
+        // large batch: uploads pinned in place and chunked, the hashes (62 % of this form) run behind them
+        PipelinedInputs pin;
+        PinnedRange r_coeffs;
+        bool used = false;
+        if (r_coeffs.pin(coeffs, coeffs ? n * 32 : 0)) {
+            const void *pc = nullptr;
+            if (coeffs) {
+                if (ctx->st_coeffs.reserve(n * 32)) return SSA_ERR_HIP;
+                HIP_TRY(hipMemcpyAsync(ctx->st_coeffs.p, coeffs, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+                pc = ctx->st_coeffs.p;     // ordered before the chunk copies whose events ctx->stream waits for
+            }
+            if (int rc = pipelined_upload_hash(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, pin, &used))
+                return rc;
+            if (used) {
+                uint32_t *d_verdict = (uint32_t *)((char *)ctx->ws_fail.p + 32);
+                if (int rc = msm_run(ctx, pin.s.sigs, pin.s.pks, pin.s.inf, pin.s.msgs, pin.s.off, msg_stride, msg_len, n,
+                                     (const u8 *)pc, 32, d_verdict, nullptr, true))
+                    return rc;
+                uint32_t v = SSA_MALFORMED;
+                HIP_TRY(hipMemcpyAsync(&v, d_verdict, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                return (int)v;
+            }
+        }
+    }
     StagedInputs s;
     const void *p;
     if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;

@@ -326,6 +326,13 @@ def test_pipelined_host_path_matches_device_path(engine, oracle):
     assert (st_h[bad] == 2).all()
     samp = np.concatenate([bad[:200], np.arange(0, n, 997)])
     assert (st_h[samp] == oracle.verify_many(sigs[samp], pks[samp], msgs[samp], check_torsion=False)).all()
+    # the MSM form from host buffers shares the upload + hash pipeline
+    co = coeffs32(rng, n)
+    assert engine.verify_batch_msm(sigs, pks, msgs, coeffs=co) == 2
+    good = sigs.copy()
+    good[bad, 60] ^= 2
+    assert engine.verify_batch_msm(good, pks, msgs, coeffs=co) == 0
+    assert engine.verify_batch_msm(good, pks, msgs) == 0                       # library-drawn coefficients
     # variable-length messages through offsets take the same path
     lens = rng.integers(0, 90, size=n)
     off = np.zeros(n + 1, np.uint64)
