@@ -30,8 +30,8 @@ while time.time() - t0 < budget:
     nonces = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); nonces[:, 31] &= 0x3F; nonces[:, 0] |= 1
     pks, sigs = eng.keygen_sign_many(sks, nonces, flat, offsets=off)
     inf = np.zeros(n, dtype=np.uint8)
-    kinds = rng.integers(0, 16, size=n)
-    for i in np.nonzero(kinds < 9)[0]:
+    kinds = rng.integers(0, 18, size=n)
+    for i in np.nonzero(kinds < 10)[0]:
         k = kinds[i]
         if k == 0:
             sigs[i, 49 + rng.integers(0, 31)] ^= 1 << rng.integers(0, 8)
@@ -52,14 +52,38 @@ while time.time() - t0 < budget:
             sigs[i, 49:81] = 0xFF
         elif k == 8:
             sigs[i, rng.integers(0, 48)] ^= 1 << rng.integers(0, 7)
-    for torsion in (True, False):
-        want = orc.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf)
+        elif k == 9:
+            sigs[i, 48] ^= 1 << rng.integers(0, 8)          # flag byte of sig.x
+    for torsion, fb in ((True, False), (False, False), (False, True)):
+        want = orc.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf, sig_flag_byte=fb)
         for mode in ("lane", "coop"):     # both kernel families
-            st, nf = eng.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf, mode=mode)
+            st, nf = eng.verify_many(sigs, pks, flat, offsets=off, check_torsion=torsion, pk_inf=inf, mode=mode,
+                                     sig_flag_byte=fb)
             if not (st == want).all() or nf != int((want != 0).sum()):
                 bad = np.nonzero(st != want)[0]
-                print("MISMATCH iteration", it, mode, "torsion", torsion, "lanes", bad[:10], st[bad[:10]], want[bad[:10]])
+                print("MISMATCH iteration", it, mode, "torsion", torsion, "flag byte", fb, "lanes", bad[:10], st[bad[:10]],
+                      want[bad[:10]])
                 sys.exit(1)
+        # keyed context, both table kinds (every signature its own key here)
+        if n <= 2000:
+            for kind in ("ladder", "comb"):
+                ks = eng.keyset_create(pks, pk_inf=inf, kind=kind)
+                st, nf = eng.verify_many_indexed(ks, np.arange(n, dtype=np.uint32), sigs, flat, offsets=off,
+                                                 check_torsion=torsion, sig_flag_byte=fb)
+                eng.keyset_destroy(ks)
+                if not (st == want).all():
+                    bad = np.nonzero(st != want)[0]
+                    print("KEYED MISMATCH iteration", it, kind, "torsion", torsion, "flag byte", fb, "lanes", bad[:10],
+                          st[bad[:10]], want[bad[:10]])
+                    sys.exit(1)
+    # MSM-form verdict on a prefix against the oracle's MSM
+    k = min(n, 40)
+    co = rng.integers(0, 256, size=(k, 32), dtype=np.uint8); co[:, 31] &= 0x3F
+    v_gpu = eng.verify_batch_msm(sigs[:k], pks[:k], flat, offsets=off[:k + 1], coeffs=co, pk_inf=inf[:k])
+    v_cpu = orc.verify_batch_msm(sigs[:k], pks[:k], flat, co, offsets=off[:k + 1], pk_inf=inf[:k])
+    if v_gpu != v_cpu:
+        print("MSM VERDICT MISMATCH iteration", it, v_gpu, v_cpu)
+        sys.exit(1)
     # decompression of the generated keys and of random x
     comp = np.zeros((min(n, 256), 49), dtype=np.uint8)
     comp[:, :48] = rng.integers(0, 256, size=(comp.shape[0], 48), dtype=np.uint8)
@@ -73,4 +97,7 @@ while time.time() - t0 < budget:
             sys.exit(1)
     total += n
     it += 1
-print("soak ok: %d iterations, %d signatures x 2 torsion settings x 2 kernel families, %.0f s" % (it, total, time.time() - t0))
+    if it % 5 == 0:
+        print("  ... %d iterations, %d signatures, %.0f s" % (it, total, time.time() - t0), flush=True)
+print("soak ok: %d iterations, %d signatures x 3 semantics x 2 kernel families (+ keyed contexts of both kinds, "
+      "MSM verdicts), %.0f s" % (it, total, time.time() - t0))
