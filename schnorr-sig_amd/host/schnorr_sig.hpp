@@ -165,6 +165,53 @@ struct KeyPair {  // src/keypair.rs:48-53
     }
 };
 
+// Many signatures by few signers (validator sets; the reference's own batch test reuses keys, src/batch.rs:152-175):
+// the key checks of Signature::verify -- canonical limbs, on the curve, subgroup check (src/signature.rs:182-184) --
+// and the tables the verification needs are computed once per key (ssa_keyset_create); verify() then checks
+// signature i against key key_idx[i] with Signature::verify's semantics.
+class KeySet {
+  public:
+    KeySet(Context &cx, const std::vector<PublicKey> &keys, uint32_t kind = SSA_KEYSET_AUTO) : cx_(cx), m_(keys.size()) {
+        std::vector<uint8_t> pks(m_ * AFFINE_PUBLIC_KEY_LENGTH), inf(m_);
+        for (size_t i = 0; i < m_; i++) {
+            std::memcpy(&pks[i * AFFINE_PUBLIC_KEY_LENGTH], keys[i].affine.data(), AFFINE_PUBLIC_KEY_LENGTH);
+            inf[i] = keys[i].is_identity ? 1 : 0;
+        }
+        int rc = ssa_keyset_create(cx.get(), pks.data(), inf.data(), m_, kind, &ks_);
+        if (rc != 0) throw std::runtime_error(std::string("ssa_keyset_create: ") + ssa_strerror(rc));
+    }
+    ~KeySet() { ssa_keyset_destroy(ks_); }
+    KeySet(const KeySet &) = delete;
+    KeySet &operator=(const KeySet &) = delete;
+    size_t size() const { return m_; }
+    // one Result per signature (a Panic for inputs the reference would panic on)
+    std::vector<Result> verify(const std::vector<Signature> &signatures, const std::vector<uint32_t> &key_idx,
+                               const std::vector<std::pair<const uint8_t *, size_t>> &messages) const {
+        const size_t n = signatures.size();
+        if (key_idx.size() != n || messages.size() != n) throw Panic("one key index and one message per signature");
+        std::vector<Result> out(n);
+        if (n == 0) return out;
+        std::vector<uint8_t> sigs(n * SIGNATURE_LENGTH), flat, status(n);
+        std::vector<uint64_t> off(n + 1, 0);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&sigs[i * SIGNATURE_LENGTH], signatures[i].bytes.data(), SIGNATURE_LENGTH);
+            flat.insert(flat.end(), messages[i].first, messages[i].first + messages[i].second);
+            off[i + 1] = flat.size();
+        }
+        flat.push_back(0);
+        int rc = ssa_verify_many_indexed(cx_.get(), ks_, key_idx.data(), sigs.data(), flat.data(), off.data(), 0, 0, n,
+                                         SSA_FLAG_CHECK_TORSION, status.data(), nullptr);
+        if (rc != 0) throw std::runtime_error(std::string("ssa_verify_many_indexed: ") + ssa_strerror(rc));
+        for (size_t i = 0; i < n; i++) out[i] = status_to_result(status[i]);
+        return out;
+    }
+
+  private:
+    Context &cx_;
+    size_t m_;
+    ssa_keyset *ks_ = nullptr;
+};
+
 // verify_batch, src/batch.rs:31-50.
 //   msm = false: AND of exact per-signature checks (`rng` unused; DESIGN.md lists the divergence classes)
 //   msm = true : the reference's own algorithm on the GPU (random linear combination + 2n-point MSM), the

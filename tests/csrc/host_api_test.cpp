@@ -86,6 +86,18 @@ int main() {
         CHECK(sc[31] <= 0x7a);
     }
     CHECK(high > 8);
+    // keyed context: the five signatures above by their three distinct signers, both table kinds
+    std::swap(pks[1], pks[2]);          // back in order
+    for (uint32_t kind : {SSA_KEYSET_LADDER, SSA_KEYSET_COMB}) {
+        KeySet set(cx, {kps[0].public_key, kps[1].public_key, kps[2].public_key}, kind);
+        std::vector<Result> res = set.verify(sigs, {0, 1, 2, 0, 0}, msgs);
+        for (const Result &x : res) CHECK(!x);
+        res = set.verify(sigs, {0, 2, 1, 0, 0}, msgs);
+        CHECK(!res[0] && res[1] && *res[1] == SignatureError::InvalidSignature && res[2] && !res[3] && !res[4]);
+        KeySet bad(cx, {small, kps[0].public_key}, kind);
+        res = bad.verify({sig, sigs[0]}, {0, 1}, {{message, sizeof message}, msgs[0]});
+        CHECK(res[0] && *res[0] == SignatureError::InvalidPublicKey && !res[1]);
+    }
     bool panicked = false;
     try {
         pks.pop_back();
