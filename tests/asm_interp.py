@@ -108,6 +108,10 @@ class Lane:
                 self.wv(a[0], ~self.rv(a[1]) & M32)
             elif op == "s_mov_b32":
                 self.salu32[int(a[0][1:])] = self.rv(a[1]) & M32
+            elif op == "s_andn2_b64":       # on carry masks: one lane's bit (SALU read of a VALU-written pair is interlocked)
+                kd, ka, kb = self._key(a[0]), self._key(a[1]), self._key(a[2])
+                self.s[kd] = self.s.get(ka, 0) & (1 - self.s.get(kb, 0))
+                self.written_at[kd] = -100  # written by the scalar unit: no VALU-write wait states
             elif op == "s_sub_u32":
                 k = int(a[0][1:])
                 self.salu32[k] = (self.salu32[k] - self.rv(a[2])) & M32

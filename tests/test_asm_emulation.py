@@ -107,6 +107,30 @@ def test_generated_fp6_blocks_on_the_cpu():
             assert got == want, (name, kind)
 
 
+def test_asm_blocks_declare_what_they_clobber():
+    """A scalar ALU instruction inside a block (s_andn2_b64, s_sub_u32, s_cmp_*) rewrites SCC: the block must say so,
+    or the compiler keeps a loop condition alive across it (a GPU hang in round 2 before the clobber was added).
+    Every fixed VGPR / SGPR the strings name must be on the clobber list too."""
+    import re
+    for path in (INC, F6_INC):
+        txt = open(path).read()
+        for m in re.finditer(r"SSA_DEV void (\w+)\(.*?asm(?: volatile)?\(\n(.*?)\n        : (.*?)\n        :(.*?)\n        : (\".*?)\);", txt, re.S):
+            name, body, clob = m.group(1), m.group(2), m.group(5)
+            clobbers = set(re.findall(r'"(\w+)"', clob))
+            if re.search(r'"s_(andn2|and|xor|or|sub|add|cmp)', body):
+                assert "scc" in clobbers, name
+            for reg in set(re.findall(r"\bv(\d+)\b", body)):
+                assert "v" + reg in clobbers, (name, "v" + reg)
+            for lo, hi in set(re.findall(r"\bv\[(\d+):(\d+)\]", body)):
+                for r in range(int(lo), int(hi) + 1):
+                    assert "v%d" % r in clobbers, (name, r)
+            for lo, hi in set(re.findall(r"\bs\[(\d+):(\d+)\]", body)):
+                for r in range(int(lo), int(hi) + 1):
+                    assert "s%d" % r in clobbers, (name, "s%d" % r)
+            if "vcc" in body:
+                assert "vcc" in clobbers, name
+
+
 def test_generated_file_is_up_to_date():
     """fp_chain_asm.inc is what tools/gen_fp_chain_asm.py generates (no hand edits)"""
     import importlib.util

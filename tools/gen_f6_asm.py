@@ -190,14 +190,18 @@ REDUCE_STEPS = [
     "v_sub_co_u32 {c0l}, {B}, {c0l}, {c2h}",          # 9  r0 = c0l - t0
     "v_subbrev_co_u32 {c2l}, {A}, 0, {c1h}, {A}",     # 10 M1 = sl - borrow(8)
     "v_subb_co_u32 {c0h}, {B}, {c0h}, {k2}, {B}",     # 11 r1 = m - th - borrow(9)
-    "v_cndmask_b32_e64 {k0}, 0, -1, {B}",             # 12 e = borrow ? EPS : 0
-    "v_sub_co_u32 {c0l}, {B}, {c0l}, {k0}",           # 13 r -= e
-    "v_subbrev_co_u32 {c0h}, {B}, 0, {c0h}, {B}",     # 14
-    "v_add_co_u32 {c0l}, {A}, {c0l}, {c1l}",          # 15 r += M
-    "v_addc_co_u32 {c0h}, {A}, {c0h}, {c2l}, {A}",    # 16
-    "v_cndmask_b32_e64 {k0}, 0, -1, {A}",             # 17 e = carry ? EPS : 0
-    "v_add_co_u32 {outl}, {A}, {c0l}, {k0}",          # 18 r += e, straight into the output operand
-    "v_addc_co_u32 {outh}, {A}, 0, {c0h}, {A}",       # 19
+    # the borrow b of (9, 11) and the carry c of (12, 13) are worth -2^64 and +2^64 = -+EPS: ONE correction by
+    # k EPS, k = c - b (round 1 fixed the borrow before adding M: one instruction more).  k = +1: r <= 2^64 - 2^33,
+    # k = -1: r > 2^64 - 2^36 >= EPS -- neither wraps again; b and c both: nothing to do.
+    "v_add_co_u32 {c0l}, {A}, {c0l}, {c1l}",          # 12 r += M
+    "v_addc_co_u32 {c0h}, {A}, {c0h}, {c2l}, {A}",    # 13
+    "s_andn2_b64 {T}, {A}, {B}",                      #    k = +1: c and not b      (scalar unit)
+    "s_andn2_b64 {B}, {B}, {A}",                      #    k = -1: b and not c
+    "v_cndmask_b32_e64 {k0}, 0, 1, {B}",              # 14 -EPS = (1, -1)
+    "v_cndmask_b32_e64 {k1}, 0, -1, {B}",             # 15
+    "v_cndmask_b32_e64 {k0}, {k0}, -1, {T}",          # 16 +EPS = (-1, 0)
+    "v_add_co_u32 {outl}, {A}, {c0l}, {k0}",          # 17 r += k EPS, straight into the output operand
+    "v_addc_co_u32 {outh}, {A}, {c0h}, {k1}, {A}",    # 18
 ]
 
 
@@ -208,7 +212,8 @@ def reduce3(accs, outs):
         for j, a in enumerate(accs):
             m = {"c0l": a.lo(0), "c0h": a.hi(0), "c1l": a.lo(1), "c1h": a.hi(1), "c2l": a.lo(2), "c2h": a.hi(2),
                  "k0": a.kk(0), "k1": a.kk(1), "k2": a.kk(2), "A": "s[%d:%d]" % (4 * j, 4 * j + 1),
-                 "B": "s[%d:%d]" % (4 * j + 2, 4 * j + 3), "outl": outs[j][0], "outh": outs[j][1]}
+                 "B": "s[%d:%d]" % (4 * j + 2, 4 * j + 3), "T": "s[%d:%d]" % (14 + 2 * j, 15 + 2 * j),
+                 "outl": outs[j][0], "outh": outs[j][1]}
             lines.append(step.format(**m))
     return lines
 
@@ -300,8 +305,8 @@ def emit(name, terms, inputs, doc, extras=()):
                 ins.append('[%sh] "v"(hi32(%s[%d]))' % (nm, arr, j))
     out.append("        : " + ",\n          ".join(ins))
     n_fixed = N_FIXED + (4 if any(sg < 0 for sg, _, _ in extras) else 0)
-    n_sgpr = 14 if bias else 12
-    clob = ['"v%d"' % r for r in POOL[:n_fixed]] + ['"s%d"' % i for i in range(n_sgpr)] + ['"vcc"']
+    n_sgpr = 20       # s[0:11] carries, s[12:13] the bias of the fused blocks, s[14:19] scratch masks of the reductions
+    clob = ['"v%d"' % r for r in POOL[:n_fixed]] + ['"s%d"' % i for i in range(n_sgpr)] + ['"vcc"', '"scc"']
     out.append("        : " + ", ".join(clob) + ");")
     for j in range(6):
         out.append("    r[%d] = mk64(r%dl, r%dh);" % (j, j, j))

@@ -53,6 +53,8 @@ def square(c):
     """(text, sgprs read, sgprs written) of one squaring of chain c, in dependency order"""
     g = regs(c)
     X, T, A, U, H, R, M, E, C, S = (g[k] for k in "XTAUHRMECS")
+    S2 = S + 8            # second carry pair of the chain: s[28:29] / s[30:31]
+    S3 = S + 16           # scratch mask: s[36:37] / s[38:39] (s32 / s33 are the stack and frame pointers)
     s = sp(S)
     return [
         ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, X), [], []),
@@ -62,22 +64,26 @@ def square(c):
         ("v_lshrrev_b64 %s, 31, %s" % (vp(H), vp(U)), [], []),
         ("v_lshl_or_b32 v%d, v%d, 1, v%d" % (T + 1, U, T + 1), [], []),           # lo = v[T:T+1]
         ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, X + 1, vp(H)), [], []),   # hi
+        # reduction: V = lo - top + EPS * h0 = X + (c - b) 2^64 with b the borrow of the subtraction and c the carry of
+        # the addition (both mod 2^64), and 2^64 = EPS: ONE correction by k EPS, k = c - b in {-1, 0, 1}
+        #   k = +1: X <= 2^64 - 2^33, no second carry;  k = -1: X >= p, no second borrow;  b and c both: nothing
         ("v_sub_co_u32 v%d, %s, v%d, v%d" % (R, s, T, H + 1), [], [S]),
         ("v_mad_u64_u32 %s, %s, v%d, -1, 0" % (vp(M), DUMMY, H), [], []),          # EPS * hi.lo
-        ("v_subbrev_co_u32 v%d, %s, 0, v%d, %s" % (R + 1, s, T + 1, s), [S], [S]),
-        ("v_cndmask_b32 v%d, 0, 1, %s" % (E, s), [S], []),                        # borrow ? p : 0
-        ("v_cndmask_b32 v%d, 0, -1, %s" % (E + 1, s), [S], []),
-        ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(R), vp(E), vp(R)), [], []),
-        ("v_add_co_u32 v%d, %s, v%d, v%d" % (X, s, R, M), [], [S]),
-        ("v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (X + 1, s, R + 1, M + 1, s), [S], [S]),
-        ("v_cndmask_b32 v%d, 0, -1, %s" % (C, s), [S], []),                       # carry ? EPS : 0; v[C+1] stays 0
-        ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(X), vp(C), vp(X)), [], []),
+        ("v_subbrev_co_u32 v%d, %s, 0, v%d, %s" % (R + 1, s, T + 1, s), [S], [S]),                  # b -> s
+        ("v_add_co_u32 v%d, %s, v%d, v%d" % (X, sp(S2), R, M), [], [S2]),
+        ("v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (X + 1, sp(S2), R + 1, M + 1, sp(S2)), [S2], [S2]),  # c -> s2
+        ("s_andn2_b64 %s, %s, %s" % (sp(S3), s, sp(S2)), [], []),                                     # k = -1: b and not c
+        ("s_andn2_b64 %s, %s, %s" % (sp(S2), sp(S2), s), [], []),                                     # k = +1: c and not b
+        ("v_cndmask_b32 v%d, 0, 1, %s" % (E, sp(S3)), [], []),                                        # -EPS = (1, -1)
+        ("v_cndmask_b32 v%d, 0, -1, %s" % (E + 1, sp(S3)), [], []),
+        ("v_cndmask_b32 v%d, v%d, -1, %s" % (E, E, sp(S2)), [], []),                                  # +EPS = (-1, 0)
+        ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(X), vp(E), vp(X)), [], []),
     ]
 
 
 def reduce_tail(c):
     """lo = v[T:T+1], hi = v[H:H+1] -> X (the last ten instructions of square())"""
-    return square(c)[7:]
+    return square(c)[7:]      # from the subtraction of hi.hi on
 
 
 def multiply(c, saved):
@@ -156,7 +162,7 @@ def emit_program(name, prog, doc):
         lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(body) else ""))
     lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1)')
     lines.append("        :")
-    clob = ['"v%d"' % r for r in range(BASE, BASE + 4 * N_PAIRS)] + ['"s%d"' % r for r in range(20, 27)] + ['"scc"', '"vcc"']
+    clob = ['"v%d"' % r for r in range(BASE, BASE + 4 * N_PAIRS)] + ['"s%d"' % r for r in list(range(20, 32)) + list(range(36, 40))] + ['"scc"', '"vcc"']
     lines.append("        : " + ", ".join(clob) + ");")
     lines += ["    x = mk64(x0, x1);", "    y = mk64(y0, y1);", "}"]
     print("%s: %d VALU instructions + %d s_nop for the two values" % (name, counts["valu"], counts["nop"]))
@@ -266,7 +272,7 @@ def main():
     progs = emit_program("inv_sbox2_asm", INV_SBOX, "x <- x^(1/7), y <- y^(1/7): the whole 63-squaring / 9-product chain of "
                          "both values in one block") + [""] + \
         emit_program("sbox2_asm", SBOX, "x <- x^7, y <- y^7")
-    clob = ['"v%d"' % r for r in used] + ['"s20"', '"s21"', '"s22"', '"s23"', '"s24"', '"s25"', '"s26"', '"scc"', '"vcc"']
+    clob = ['"v%d"' % r for r in used] + ['"s%d"' % r for r in list(range(20, 32)) + list(range(36, 40))] + ['"scc"', '"vcc"']
     lines.append("        : " + ", ".join(clob) + ");")
     lines.append("    x = mk64(x0, x1);")
     lines.append("    y = mk64(y0, y1);")
