@@ -186,22 +186,20 @@ REDUCE_STEPS = [
     "v_addc_co_u32 {c2h}, {B}, 0, {c2h}, {B}",        # 5  t0 += cb
     "v_addc_co_u32 {k2}, {A}, 0, {k2}, {A}",          # 6  th = k2 + carry(4)
     "v_addc_co_u32 {k2}, {B}, 0, {k2}, {B}",          # 7  th += carry(5)
-    "v_sub_co_u32 {c1l}, {A}, 0, {c1h}",              # 8  M0 = -sl
-    "v_sub_co_u32 {c0l}, {B}, {c0l}, {c2h}",          # 9  r0 = c0l - t0
-    "v_subbrev_co_u32 {c2l}, {A}, 0, {c1h}, {A}",     # 10 M1 = sl - borrow(8)
-    "v_subb_co_u32 {c0h}, {B}, {c0h}, {k2}, {B}",     # 11 r1 = m - th - borrow(9)
-    # the borrow b of (9, 11) and the carry c of (12, 13) are worth -2^64 and +2^64 = -+EPS: ONE correction by
-    # k EPS, k = c - b (round 1 fixed the borrow before adding M: one instruction more).  k = +1: r <= 2^64 - 2^33,
-    # k = -1: r > 2^64 - 2^36 >= EPS -- neither wraps again; b and c both: nothing to do.
-    "v_add_co_u32 {c0l}, {A}, {c0l}, {c1l}",          # 12 r += M
-    "v_addc_co_u32 {c0h}, {A}, {c0h}, {c2l}, {A}",    # 13
+    # r = (c0l, m) + EPS * sl - (t0, th): the multiply-add takes (c0l, m) as its 64-bit addend and delivers the carry
+    # c; the subtraction delivers the borrow b; they are worth +2^64 and -2^64 = +-EPS: ONE correction by k EPS,
+    # k = c - b.  k = +1: r <= 2^64 - 2^33, k = -1: r > 2^64 - 2^36 >= EPS -- neither wraps again; both: nothing.
+    # (Round 1: M = EPS * sl by two subtractions, borrow fix, 64-bit add, carry fix: 19 instructions, now 15.)
+    "v_mad_u64_u32 {c0p}, {A}, {c1h}, -1, {c0p}",     # 8  r = (c0l, m) + EPS * sl, carry c
+    "v_sub_co_u32 {c0l}, {B}, {c0l}, {c2h}",          # 9  r -= (t0, th), borrow b
+    "v_subb_co_u32 {c0h}, {B}, {c0h}, {k2}, {B}",     # 10
     "s_andn2_b64 {T}, {A}, {B}",                      #    k = +1: c and not b      (scalar unit)
     "s_andn2_b64 {B}, {B}, {A}",                      #    k = -1: b and not c
-    "v_cndmask_b32_e64 {k0}, 0, 1, {B}",              # 14 -EPS = (1, -1)
-    "v_cndmask_b32_e64 {k1}, 0, -1, {B}",             # 15
-    "v_cndmask_b32_e64 {k0}, {k0}, -1, {T}",          # 16 +EPS = (-1, 0)
-    "v_add_co_u32 {outl}, {A}, {c0l}, {k0}",          # 17 r += k EPS, straight into the output operand
-    "v_addc_co_u32 {outh}, {A}, {c0h}, {k1}, {A}",    # 18
+    "v_cndmask_b32_e64 {k0}, 0, 1, {B}",              # 11 -EPS = (1, -1)
+    "v_cndmask_b32_e64 {k1}, 0, -1, {B}",             # 12
+    "v_cndmask_b32_e64 {k0}, {k0}, -1, {T}",          # 13 +EPS = (-1, 0)
+    "v_add_co_u32 {outl}, {A}, {c0l}, {k0}",          # 14 r += k EPS, straight into the output operand
+    "v_addc_co_u32 {outh}, {A}, {c0h}, {k1}, {A}",    # 15
 ]
 
 
@@ -210,7 +208,7 @@ def reduce3(accs, outs):
     lines = []
     for step in REDUCE_STEPS:
         for j, a in enumerate(accs):
-            m = {"c0l": a.lo(0), "c0h": a.hi(0), "c1l": a.lo(1), "c1h": a.hi(1), "c2l": a.lo(2), "c2h": a.hi(2),
+            m = {"c0p": a.pair(0), "c0l": a.lo(0), "c0h": a.hi(0), "c1l": a.lo(1), "c1h": a.hi(1), "c2l": a.lo(2), "c2h": a.hi(2),
                  "k0": a.kk(0), "k1": a.kk(1), "k2": a.kk(2), "A": "s[%d:%d]" % (4 * j, 4 * j + 1),
                  "B": "s[%d:%d]" % (4 * j + 2, 4 * j + 3), "T": "s[%d:%d]" % (14 + 2 * j, 15 + 2 * j),
                  "outl": outs[j][0], "outh": outs[j][1]}

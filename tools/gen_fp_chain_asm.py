@@ -67,11 +67,10 @@ def square(c):
         # reduction: V = lo - top + EPS * h0 = X + (c - b) 2^64 with b the borrow of the subtraction and c the carry of
         # the addition (both mod 2^64), and 2^64 = EPS: ONE correction by k EPS, k = c - b in {-1, 0, 1}
         #   k = +1: X <= 2^64 - 2^33, no second carry;  k = -1: X >= p, no second borrow;  b and c both: nothing
-        ("v_sub_co_u32 v%d, %s, v%d, v%d" % (R, s, T, H + 1), [], [S]),
-        ("v_mad_u64_u32 %s, %s, v%d, -1, 0" % (vp(M), DUMMY, H), [], []),          # EPS * hi.lo
-        ("v_subbrev_co_u32 v%d, %s, 0, v%d, %s" % (R + 1, s, T + 1, s), [S], [S]),                  # b -> s
-        ("v_add_co_u32 v%d, %s, v%d, v%d" % (X, sp(S2), R, M), [], [S2]),
-        ("v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (X + 1, sp(S2), R + 1, M + 1, sp(S2)), [S2], [S2]),  # c -> s2
+        # lo + EPS * hi.lo in ONE multiply-add (the 64-bit addend is lo, the carry-out c goes to s2), then - hi.hi
+        ("v_mad_u64_u32 %s, %s, v%d, -1, %s" % (vp(X), sp(S2), H, vp(T)), [], [S2]),
+        ("v_sub_co_u32 v%d, %s, v%d, v%d" % (X, s, X, H + 1), [], [S]),
+        ("v_subbrev_co_u32 v%d, %s, 0, v%d, %s" % (X + 1, s, X + 1, s), [S], [S]),                  # b -> s
         ("s_andn2_b64 %s, %s, %s" % (sp(S3), s, sp(S2)), [], []),                                     # k = -1: b and not c
         ("s_andn2_b64 %s, %s, %s" % (sp(S2), sp(S2), s), [], []),                                     # k = +1: c and not b
         ("v_cndmask_b32 v%d, 0, 1, %s" % (E, sp(S3)), [], []),                                        # -EPS = (1, -1)
