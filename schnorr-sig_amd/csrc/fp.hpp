@@ -65,17 +65,22 @@ SSA_DEV bool fp_eq(u64 a, u64 b) { return fp_canon(a) == fp_canon(b); }
 // carry-free form (0 - h, h - min(h, 1)) 13 % slower (ssa_k_hash 14.6 -> 16.5 ms).
 SSA_DEV u64 eps_times(u32 h) { return ((u64)h << 32) - h; }
 
-// Reduce lo + 2^64*(h0 + 2^32*h1), h1 < 2^64 allowed as a full 64-bit "top" value:
-// value = lo + EPS*h0 - (top),  top = h1 + 2^32*h2 given as a u64.
+// Reduce lo + 2^64*(h0 + 2^32*h1), h1 given as a 64-bit "top" value (top < 2^63):
+//   V = lo + EPS*h0 - top.
+// One multiply-add computes lo + EPS*h0 (the 64-bit addend is lo; a carry c is worth +2^64 = +EPS), the
+// subtraction of top may borrow (b, worth -EPS), and ONE correction by (c - b)*EPS finishes:
+//   c only:  r <= 2^64 - 2^33, adding EPS cannot carry again;   b only:  r >= 2^64 - top > EPS, no second borrow;
+//   both: they cancel.  (Round 1 fixed the borrow, added EPS*h0 separately and fixed the carry: three 64-bit
+//   additions and two compares more -- the same restructuring as in the generated asm blocks.)
 SSA_DEV u64 fp_reduce_parts(u64 lo, u32 h0, u64 top) {
-    u64 t = lo - top;
-    u32 bw = lo < top;
-    t -= bw ? (u64)FP_EPS : 0ull;            // no second borrow: t >= 2^64 - top > EPS here
-    u64 m = eps_times(h0);                   // EPS * h0
-    u64 r = t + m;
-    u32 c = r < t;
-    r += c ? (u64)FP_EPS : 0ull;             // cannot carry again (m <= 2^64 - 2^33 + 1)
-    return r;
+    const u64 r = (u64)h0 * (u64)FP_EPS + lo;    // v_mad_u64_u32 with a 64-bit addend
+    const bool c = r < lo;
+    const u64 d = r - top;
+    const bool b = r < top;
+    u64 corr = 0ull;
+    if (c && !b) corr = (u64)FP_EPS;
+    if (b && !c) corr = 0ull - (u64)FP_EPS;      // = p (mod 2^64)
+    return d + corr;
 }
 
 SSA_DEV u64 fp_reduce128(u64 lo, u64 hi) { return fp_reduce_parts(lo, lo32(hi), (u64)hi32(hi)); }
