@@ -130,22 +130,49 @@ SSA_DEV fp6 f6_mul(const fp6 &a, const fp6 &b) {
                        b.c[4], b.c[5]);
 }
 
+// Pre-scaled operands of the squaring blocks: a2[j] = 2 a[j] (j = 1..5), a7[j] = 7 a[j] (j = 3..5), a14[j] = 14 a[j]
+// (j = 4, 5).  Doubling a loose value is a shift plus EPS for the top bit, and the sum wraps a second time only for
+// a >= 2^64 - 2^31, i.e. when the high word is all ones: one max over the seven high words guards the two-instruction
+// doubling, the three-instruction second fix-up of fp_dbl runs in the (never taken) cold branch.
+SSA_DEV u64 fp_dbl_nowrap(u64 a) { return (a << 1) + (u64)(u32)((int)hi32(a) >> 31); }
+SSA_DEV void f6_sqr_scale(const u64 (&a)[6], u64 (&a2)[6], u64 (&a7)[6], u64 (&a14)[6]) {
+    a2[0] = 0ull;
+#pragma unroll
+    for (int j = 0; j < 3; j++) a7[j] = a14[j] = 0ull;
+    a14[3] = 0ull;     // no term uses it
+#pragma unroll
+    for (int j = 3; j < 6; j++) a7[j] = fp_mul_small(a[j], 7u);
+#ifdef SSA_PLAIN_PRESCALE
+#pragma unroll
+    for (int j = 1; j < 6; j++) a2[j] = fp_dbl(a[j]);
+#pragma unroll
+    for (int j = 4; j < 6; j++) a14[j] = fp_dbl(a7[j]);
+#else
+    u32 g = hi32(a[1]);
+#pragma unroll
+    for (int j = 2; j < 6; j++) g = g > hi32(a[j]) ? g : hi32(a[j]);
+#pragma unroll
+    for (int j = 4; j < 6; j++) g = g > hi32(a7[j]) ? g : hi32(a7[j]);
+#pragma unroll
+    for (int j = 1; j < 6; j++) a2[j] = fp_dbl_nowrap(a[j]);
+#pragma unroll
+    for (int j = 4; j < 6; j++) a14[j] = fp_dbl_nowrap(a7[j]);
+    if (__builtin_expect(g == 0xffffffffu, 0)) {
+#pragma unroll
+        for (int j = 1; j < 6; j++) a2[j] = fp_dbl(a[j]);
+#pragma unroll
+        for (int j = 4; j < 6; j++) a14[j] = fp_dbl(a7[j]);
+    }
+#endif
+}
+
 // squaring: 21 products; off-diagonal terms use 2a_j (direct) or 14a_j (wrapped),
 // diagonal terms a_i (direct) or 7a_i (wrapped).
 SSA_FN fp6 f6_sqr_flat(u64 a0, u64 a1, u64 a2_, u64 a3, u64 a4, u64 a5) {
     fp6 a;
     a.c[0] = a0; a.c[1] = a1; a.c[2] = a2_; a.c[3] = a3; a.c[4] = a4; a.c[5] = a5;
     u64 a2[6], a7[6], a14[6];
-    a2[0] = 0ull;
-#pragma unroll
-    for (int j = 0; j < 3; j++) a7[j] = a14[j] = 0ull;
-#pragma unroll
-    for (int j = 1; j < 6; j++) a2[j] = fp_dbl(a.c[j]);
-#pragma unroll
-    for (int j = 3; j < 6; j++) {
-        a7[j] = fp_mul_small(a.c[j], 7u);
-        a14[j] = fp_dbl(a7[j]);
-    }
+    f6_sqr_scale(a.c, a2, a7, a14);
 #ifdef SSA_F6_ASM
     fp6 r;
     f6_sqr_core_asm(a.c, a2, a7, a14, r.c);
@@ -188,16 +215,7 @@ SSA_DEV fp6 f6_sqr(const fp6 &a) { return f6_sqr_flat(a.c[0], a.c[1], a.c[2], a.
 SSA_DEV fp6 f6_sqr_inl(const fp6 &a) {
 #ifdef SSA_F6_ASM
     u64 a2[6], a7[6], a14[6];
-    a2[0] = 0ull;
-#pragma unroll
-    for (int j = 0; j < 3; j++) a7[j] = a14[j] = 0ull;
-#pragma unroll
-    for (int j = 1; j < 6; j++) a2[j] = fp_dbl(a.c[j]);
-#pragma unroll
-    for (int j = 3; j < 6; j++) {
-        a7[j] = fp_mul_small(a.c[j], 7u);
-        a14[j] = fp_dbl(a7[j]);
-    }
+    f6_sqr_scale(a.c, a2, a7, a14);
     fp6 r;
     f6_sqr_core_asm(a.c, a2, a7, a14, r.c);
     return r;
@@ -212,16 +230,7 @@ SSA_DEV fp6 f6_sqr_inl(const fp6 &a) {
 // of the ~10 of a modular addition).  Inlined at their call sites (one each in jac_dbl / jac_madd): no call, no
 // argument moves.  Host build and -DSSA_NO_F6_ASM: the same value from the plain operations.
 SSA_DEV void f6_sqr_prescale(const fp6 &a, u64 (&a2)[6], u64 (&a7)[6], u64 (&a14)[6]) {
-    a2[0] = 0ull;
-#pragma unroll
-    for (int j = 0; j < 3; j++) a7[j] = a14[j] = 0ull;
-#pragma unroll
-    for (int j = 1; j < 6; j++) a2[j] = fp_dbl(a.c[j]);
-#pragma unroll
-    for (int j = 3; j < 6; j++) {
-        a7[j] = fp_mul_small(a.c[j], 7u);
-        a14[j] = fp_dbl(a7[j]);
-    }
+    f6_sqr_scale(a.c, a2, a7, a14);
 }
 SSA_DEV void f6_mul_prescale(const fp6 &b, u64 (&b7)[6]) {
     b7[0] = 0ull;
