@@ -71,6 +71,24 @@ SSA_DEV jac jac_dbl(const jac &p) {
 }
 #endif
 
+// n >= 1 consecutive doublings.  Device code: ONE generated asm statement (jac_asm.inc, tools/gen_jac_asm.py: the
+// point in pinned VGPRs, hand-assigned temporaries, pre-scaled operands shared between the blocks, guarded short
+// forms of 2a / 7a).  -DSSA_NO_JAC_ASM and the host build: the compiled doubling in a loop.
+#if defined(SSA_F6_ASM) && !defined(SSA_NO_JAC_ASM)
+#define SSA_JAC_ASM 1
+#include "jac_asm.inc"
+#endif
+SSA_DEV jac jac_dbl_n(jac p, u32 n) {
+#ifdef SSA_JAC_ASM
+    jac_dbl_n_asm(p.X.c, p.Y.c, p.Z.c, n);
+    return p;
+#else
+#pragma unroll 1
+    for (u32 d = 0; d < n; d++) p = jac_dbl(p);
+    return p;
+#endif
+}
+
 // the doubling as a shared out-of-line body for the rare P == Q branches of the additions (-DSSA_MADD_COLD_DBL).
 // Measured and NOT the default: the call in the middle of the addition costs the register allocator more than the
 // never-executed inlined copy costs in code size (ssa_k_verify 36.6 vs 35.5 ms, msm_k_buckets 4.5 vs 3.6 ms).

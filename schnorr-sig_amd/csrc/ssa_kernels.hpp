@@ -312,8 +312,7 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k) {
     }
 #pragma unroll 1
     for (int w = 62; w >= 0; w--) {
-#pragma unroll 1
-        for (int d = 0; d < 4; d++) acc = jac_dbl(acc);
+        acc = jac_dbl_n(acc, 4u);
         const int digit = (int)sc_nibble(kr, (u32)w) - 8;
         if (digit != 0) {
             const int mag = digit < 0 ? -digit : digit;
@@ -982,7 +981,8 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
 
 // [k]P with the production table code path (op 4): a = k (4 u64), b = P (12 u64 + inf)
 #ifndef SSA_NO_KERNELS
-__global__ void ssa_k_debug_mul(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
+__global__ void __launch_bounds__(256, 2)      // the asm doubling owns VGPRs up to v255: two waves per SIMD at most
+ssa_k_debug_mul(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
                                 size_t as, size_t bs, u64 *__restrict__ ws_tab,
                                 u64 *__restrict__ out, size_t os) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

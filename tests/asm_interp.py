@@ -98,6 +98,7 @@ class Lane:
                 continue
             self.issued += 1
             if ln.startswith("s_nop"):
+                self.issued += int(ln.split()[1])        # s_nop N = N + 1 wait states
                 continue
             op, rest = ln.split(None, 1)
             op = op.replace("_e64", "").replace("_e32", "")
@@ -120,6 +121,29 @@ class Lane:
             elif op == "s_cbranch_scc1":
                 if scc:
                     pc = labels[a[0]]
+            elif op == "s_cbranch_vccnz":    # one lane: the branch is taken when this lane's bit is set
+                if self.s.get("vcc", 0):
+                    pc = labels[a[0]]
+            elif op == "s_branch":
+                pc = labels[a[0]]
+            elif op == "s_and_b64":
+                kd, ka, kb = self._key(a[0]), self._key(a[1]), self._key(a[2])
+                self.s[kd] = self.s.get(ka, 0) & self.s.get(kb, 0)
+                self.written_at[kd] = -100
+            elif op in ("v_cmp_le_u32", "v_cmp_eq_u32", "v_cmp_ne_u32"):
+                x, y = self.rv(a[1]), self.rv(a[2])
+                self.wc(a[0], int({"le": x <= y, "eq": x == y, "ne": x != y}[op[6:8]]))
+            elif op == "v_mul_lo_u32":
+                self.wv(a[0], (self.rv(a[1]) * self.rv(a[2])) & M32)
+            elif op == "v_mul_hi_u32":
+                self.wv(a[0], (self.rv(a[1]) * self.rv(a[2])) >> 32)
+            elif op == "v_max_u32":
+                self.wv(a[0], max(self.rv(a[1]), self.rv(a[2])))
+            elif op == "v_max3_u32":
+                self.wv(a[0], max(self.rv(a[1]), self.rv(a[2]), self.rv(a[3])))
+            elif op == "v_ashrrev_i32":
+                x = self.rv(a[2])
+                self.wv(a[0], ((x - (1 << 32) if x >> 31 else x) >> int(a[1])) & M32)
             elif op == "v_mad_u64_u32":
                 r = self.rv(a[2]) * self.rv(a[3]) + self.rv(a[4])
                 if a[1].strip() in self.dummy:

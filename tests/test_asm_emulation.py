@@ -131,6 +131,131 @@ def test_asm_blocks_declare_what_they_clobber():
                 assert "vcc" in clobbers, name
 
 
+JAC_INC = os.path.join(os.path.dirname(INC), "jac_asm.inc")
+
+
+def _jac_lines():
+    txt = open(JAC_INC).read()
+    am = re.search(r"asm volatile\(\n(.*?)\n        : ", txt, re.S)
+    return [ln.strip().strip('"').replace("\\n\\t", "") for ln in am.group(1).split("\n") if ln.strip()], txt
+
+
+def _jac_dbl_model(X, Y, Z):
+    """dbl-2007-bl with a = 1 on plain integers (the formulas of curve.hpp's compiled jac_dbl)"""
+    add = lambda u, v: [(a + b) % P for a, b in zip(u, v)]
+    sub = lambda u, v: [(a - b) % P for a, b in zip(u, v)]
+    sc = lambda c, u: [c * a % P for a in u]
+    XX, YY, ZZ = _f6_mulmod(X, X), _f6_mulmod(Y, Y), _f6_mulmod(Z, Z)
+    YYYY = _f6_mulmod(YY, YY)
+    t = add(X, YY)
+    S = sc(2, sub(sub(_f6_mulmod(t, t), XX), YYYY))
+    M = add(sc(3, XX), _f6_mulmod(ZZ, ZZ))
+    X3 = sub(_f6_mulmod(M, M), sc(2, S))
+    Y3 = sub(_f6_mulmod(M, sub(S, X3)), sc(8, YYYY))
+    yz = add(Y, Z)
+    return X3, Y3, sub(sub(_f6_mulmod(yz, yz), YY), ZZ)
+
+
+def test_generated_doubling_on_the_cpu():
+    """jac_asm.inc (n doublings as one asm statement) through the interpreter against the textbook formulas: random,
+    edge and all-ones operands, and operands whose high words are all ones so that every guarded pre-scaling site takes
+    its cold path; carry wait states checked on the way"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_jac_asm as gj
+    lines, _ = _jac_lines()
+    rnd = random.Random(21)
+    edge = [0, 1, P - 1, P, 2**64 - 1, 2**32 - 1, 2**32, 2**64 - 2**32, 2**64 - 2**31, 2**63, 2**64 - 5]
+
+    def elem(kind):
+        if kind == "edge":
+            return [rnd.choice(edge) for _ in range(6)]
+        if kind == "max":
+            return [2**64 - 1] * 6
+        if kind == "zero":
+            return [0] * 6
+        if kind == "hi":
+            return [(0xFFFFFFFF << 32) | rnd.randrange(2**32) for _ in range(6)]
+        if kind == "near":       # c * a_hi lands within a few units of 2^32 for c = 3, 6, 7, 21: the multiples' guards
+            out = []
+            for _ in range(6):
+                c = rnd.choice([3, 7, 21])
+                hi = (2**32 - rnd.randrange(1, 64)) * pow(c, -1, 2**32) % 2**32
+                out.append((hi << 32) | rnd.choice([rnd.randrange(2**32), 0xFFFFFFFF, 0]))
+            return out
+        return [rnd.randrange(2**64) for _ in range(6)]
+
+    cold_seen = 0
+    for kind in ["rand"] * 3 + ["edge"] * 5 + ["max", "zero", "hi", "hi", "hi", "near", "near", "near"]:
+        for n in (1, 3):
+            pt = [elem(kind), elem("rand" if kind == "zero" else kind), elem(kind)]
+            lane = ai.Lane({"%[n]": n})
+            for regs, val in zip((gj.XR, gj.YR, gj.ZR), pt):
+                for j in range(6):
+                    lane.v[regs[j]], lane.v[regs[j] + 1] = val[j] & M32, val[j] >> 32
+            lane.run(lines)
+            cold_seen += lane.issued > n * 3200
+            got = [[(lane.v[r] | (lane.v[r + 1] << 32)) % P for r in regs] for regs in (gj.XR, gj.YR, gj.ZR)]
+            want = pt
+            for _ in range(n):
+                want = _jac_dbl_model(*want)
+            assert got == [list(w) for w in want], (kind, n)
+    assert cold_seen >= 6         # the cold paths did run
+
+
+def test_doubling_prescale_sites_fast_and_cold():
+    """one pre-scaling site in isolation (2a, c a, 2 c a): the short forms and, for operands that trip the guard, the
+    exact cold forms"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_jac_asm as gj
+    rnd = random.Random(4)
+    for trial in range(600):
+        gen = gj.Gen()
+        src, PB = gj.XR, gen.PB
+        c = rnd.choice([3, 6, 7, 21])
+        gen.prescale(src, [(PB[0], 0)], [(PB[1], 1, c), (PB[2], 2, c)], [(PB[3], PB[1])])
+        lines = ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + gen.main + ["s_branch L_end"] + gen.cold + ["L_end:"]
+        lane = ai.Lane({})
+        vals = []
+        for j in range(3):
+            kind = trial % 3
+            if kind == 0:
+                v = rnd.randrange(2**64)
+            elif kind == 1:
+                v = (0xFFFFFFFF << 32) | rnd.choice([rnd.randrange(2**32), 0, 1, 0xFFFFFFFF])
+            else:
+                hi = (2**32 - rnd.randrange(1, 300)) * pow(c | 1, -1, 2**32) % 2**32
+                v = (hi << 32) | rnd.choice([rnd.randrange(2**32), 0xFFFFFFFF, 0])
+            vals.append(v)
+            lane.v[src[j]], lane.v[src[j] + 1] = v & M32, v >> 32
+        lane.run(lines)
+        rd = lambda p: lane.v[p] | (lane.v[p + 1] << 32)
+        assert rd(src[0]) % P == vals[0] % P                  # canonicalised in place at most
+        assert rd(PB[0]) % P == 2 * vals[0] % P and rd(PB[1]) % P == c * vals[1] % P
+        assert rd(PB[2]) % P == c * vals[2] % P and rd(PB[3]) % P == 2 * c * vals[1] % P, (trial, c)
+
+
+def test_doubling_asm_declares_its_registers_and_kernels_leave_room():
+    """every VGPR / SGPR the doubling names is pinned or on the clobber list, SCC and VCC are declared, and every
+    kernel that inlines it is built for at most two waves per SIMD (the block owns registers up to v255)"""
+    lines, txt = _jac_lines()
+    clob = set(re.findall(r'"(\w+)"', txt.split("\n        : [n]")[1]))
+    pinned = set()
+    for lo, hi in re.findall(r'"\+\{v\[(\d+):(\d+)\]\}"', txt):
+        pinned.update(range(int(lo), int(hi) + 1))
+    body = "\n".join(lines)
+    for reg in set(re.findall(r"\bv(\d+)\b", body)):
+        assert "v" + reg in clob or int(reg) in pinned, reg
+    for lo, hi in set(re.findall(r"\bv\[(\d+):(\d+)\]", body)):
+        assert int(lo) % 2 == 0 and all("v%d" % r in clob or r in pinned for r in range(int(lo), int(hi) + 1)), lo
+    for lo, hi in set(re.findall(r"\bs\[(\d+):(\d+)\]", body)):
+        assert all("s%d" % r in clob for r in range(int(lo), int(hi) + 1)), lo
+    assert {"scc", "vcc", "s20"} <= clob
+    src = open(os.path.join(os.path.dirname(INC), "ssa_kernels.hpp")).read()
+    for m in re.finditer(r"__global__ void\s*(__launch_bounds__\(([^)]*)\))?[^{;]*?\b(ssa_k_\w+)\(.*?\n}\n", src, re.S):
+        if "mul_ptab(" in m.group(0) or "jac_dbl_n(" in m.group(0):
+            assert m.group(2) and m.group(2).replace(" ", "").endswith(",2"), m.group(3)
+
+
 def test_generated_file_is_up_to_date():
     """fp_chain_asm.inc is what tools/gen_fp_chain_asm.py generates (no hand edits)"""
     import importlib.util
@@ -144,3 +269,11 @@ def test_generated_file_is_up_to_date():
     with redirect_stdout(io.StringIO()):
         mod.main()
     assert open(INC).read() == before
+    before = open(JAC_INC).read()
+    spec = importlib.util.spec_from_file_location("gen_jac_asm", os.path.join(root, "tools", "gen_jac_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    spec.loader.exec_module(mod)
+    with redirect_stdout(io.StringIO()):
+        mod.main()
+    assert open(JAC_INC).read() == before
