@@ -145,6 +145,19 @@ SSA_DEV jac jac_madd(const jac &p, const aff &q) {
     return r;
 }
 
+// The mixed addition of the hot loops: the generated asm block (jac_asm.inc) for the generic case; when it reports a
+// possible exceptional input (identity, P == +-Q: a first coefficient = 0 mod p, never for honest inputs) the whole
+// wave runs the compiled, exact jac_madd above on the untouched point.
+SSA_DEV jac jac_madd_fast(const jac &p, const aff &q) {
+#ifdef SSA_JAC_ASM
+    jac r = p;
+    if (jac_madd_asm(r.X.c, r.Y.c, r.Z.c, q.x.c, q.y.c)) return r;
+    return jac_madd(r, q);          // r is untouched (at most canonicalised): no copy of p has to be kept
+#else
+    return jac_madd(p, q);
+#endif
+}
+
 // general addition p + q (both Jacobian): 11M + 5S on the generic path
 SSA_DEV jac jac_add(const jac &p, const jac &q) {
     fp6 Z1Z1 = f6_sqr(p.Z);

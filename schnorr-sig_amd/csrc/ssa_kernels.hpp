@@ -28,6 +28,7 @@ constexpr int PTAB_ENTRIES = 8;
 // a table row is 256 B = two 128-B lines: X, Y (affine x, y after the build) in the first -- a gather of the
 // ladder touches exactly one line -- and Z, prefix product of the build in the second
 constexpr int PTAB_ENTRY_U64 = 32, PTAB_Z = 16, PTAB_C = 22;
+constexpr int PTAB_NY = 16;     // finished table: -y in the slot Z occupied during the build (the ladder never negates)
 
 constexpr u32 ST_OK = 0, ST_INVALID_PK = 1, ST_INVALID_SIG = 2, ST_MALFORMED = 3;
 
@@ -257,7 +258,10 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
         z.x = f6_zero();
         z.y = f6_zero();
 #pragma unroll 1
-        for (int e = 0; e < PTAB_ENTRIES; e++) st_aff(tab + e * R, z);
+        for (int e = 0; e < PTAB_ENTRIES; e++) {
+            st_aff(tab + e * R, z);
+            st_f6(tab + e * R + PTAB_NY, z.y);
+        }
         return;
     }
     st_row(tab, jac_from_aff(p));                 // row 0 doubles as affine P: (x, y, Z = 1)
@@ -296,7 +300,9 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
             a.y = f6_zero();
         }
         st_aff(tab + e * R, a);
+        st_f6(tab + e * R + PTAB_NY, f6_neg(a.y));
     }
+    st_f6(tab + PTAB_NY, f6_neg(p.y));
 }
 
 // [k]P, k < 2^255, from the lane's affine table with signed 4-bit windows (offset recoding):
@@ -312,14 +318,26 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k) {
     }
 #pragma unroll 1
     for (int w = 62; w >= 0; w--) {
-        acc = jac_dbl_n(acc, 4u);
         const int digit = (int)sc_nibble(kr, (u32)w) - 8;
+        const int mag = digit < 0 ? -digit : digit;
+#ifdef SSA_JAC_ASM
+        // one asm statement per window: 4 doublings + the addition on the lanes with a non-zero digit; -y comes from
+        // the table, so the loop body outside the statement is the digit, one address and six loads
+        const u64 *row = tab + (size_t)((mag ? mag : 1) - 1) * PTAB_ENTRY_U64;
+        aff q;
+        q.x = ld_f6(row);
+        q.y = ld_f6(row + (digit < 0 ? PTAB_NY : 6));
+        if (!jac_window_asm(acc.X.c, acc.Y.c, acc.Z.c, q.x.c, q.y.c, (u32)mag, 4u)) {
+            if (digit != 0) acc = jac_madd(acc, q);      // exceptional inputs: the exact compiled addition
+        }
+#else
+        acc = jac_dbl_n(acc, 4u);
         if (digit != 0) {
-            const int mag = digit < 0 ? -digit : digit;
             aff q = ld_aff(tab + (mag - 1) * PTAB_ENTRY_U64);
             q.y = f6_select(digit < 0, q.y, f6_neg(q.y));
-            acc = jac_madd(acc, q);
+            acc = jac_madd_fast(acc, q);
         }
+#endif
     }
     return acc;
 }
@@ -331,7 +349,7 @@ SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e) 
         const u32 d = sc_win16(e, (u32)w);
         if (d != 0) {
             const aff q = ld_aff(gtab + (((size_t)w << GW_BITS) + d) * 12);
-            acc = jac_madd(acc, q);
+            acc = jac_madd_fast(acc, q);
         }
     }
     return acc;
@@ -597,7 +615,7 @@ ssa_k_verify_keyed_comb(const u8 *__restrict__ sigs, const u32 *__restrict__ key
                 if (wi == 2) word = h.w[2];
                 if (wi == 3) word = h.w[3];
                 const u32 d = (u32)(word >> ((w & 7) * 8)) & 0xffu;
-                if (d != 0) r = jac_madd(r, ld_aff(tab + (((size_t)w << KW_BITS) + d) * 12));
+                if (d != 0) r = jac_madd_fast(r, ld_aff(tab + (((size_t)w << KW_BITS) + d) * 12));
             }
             r = add_base_mul(r, gtab, e);
             bool eq;

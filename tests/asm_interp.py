@@ -124,6 +124,15 @@ class Lane:
             elif op == "s_cbranch_vccnz":    # one lane: the branch is taken when this lane's bit is set
                 if self.s.get("vcc", 0):
                     pc = labels[a[0]]
+            elif op == "s_and_saveexec_b64":   # one lane: EXEC is this lane's bit
+                self.exec_saved = getattr(self, "exec_bit", 1)
+                self.exec_bit = self.exec_saved & self.s.get(self._key(a[1]), 0)
+            elif op == "s_cbranch_execz":
+                if not getattr(self, "exec_bit", 1):
+                    pc = labels[a[0]]
+            elif op == "s_mov_b64":
+                assert a[0] == "exec"
+                self.exec_bit = self.exec_saved
             elif op == "s_branch":
                 pc = labels[a[0]]
             elif op == "s_and_b64":
@@ -137,6 +146,12 @@ class Lane:
                 self.wv(a[0], (self.rv(a[1]) * self.rv(a[2])) & M32)
             elif op == "v_mul_hi_u32":
                 self.wv(a[0], (self.rv(a[1]) * self.rv(a[2])) >> 32)
+            elif op == "v_or_b32":
+                self.wv(a[0], self.rv(a[1]) | self.rv(a[2]))
+            elif op == "v_xor_b32":
+                self.wv(a[0], self.rv(a[1]) ^ self.rv(a[2]))
+            elif op == "v_min_u32":
+                self.wv(a[0], min(self.rv(a[1]), self.rv(a[2])))
             elif op == "v_max_u32":
                 self.wv(a[0], max(self.rv(a[1]), self.rv(a[2])))
             elif op == "v_max3_u32":

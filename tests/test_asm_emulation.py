@@ -202,6 +202,97 @@ def test_generated_doubling_on_the_cpu():
     assert cold_seen >= 6         # the cold paths did run
 
 
+def _f6_sub(u, v):
+    return [(a - b) % P for a, b in zip(u, v)]
+
+
+def _jac_madd_model(X, Y, Z, x2, y2):
+    ZZ = _f6_mulmod(Z, Z)
+    H = _f6_sub(_f6_mulmod(x2, ZZ), X)
+    R = _f6_sub(_f6_mulmod(_f6_mulmod(y2, Z), ZZ), Y)
+    HH = _f6_mulmod(H, H)
+    HHH, V = _f6_mulmod(H, HH), _f6_mulmod(X, HH)
+    X3 = _f6_sub(_f6_sub(_f6_mulmod(R, R), HHH), [2 * v % P for v in V])
+    Y3 = _f6_sub(_f6_mulmod(R, _f6_sub(V, X3)), _f6_mulmod(Y, HHH))
+    return [X3, Y3, _f6_mulmod(Z, H)], H
+
+
+def _asm_fn(txt, name):
+    fn = txt.split("SSA_DEV u32 %s" % name)[1].split("\n}\n")[0]
+    am = re.search(r"asm volatile\(\n(.*?)\n        : ", fn, re.S)
+    lines = [ln.strip().strip('"').replace("\\n\\t", "") for ln in am.group(1).split("\n") if ln.strip()]
+    ins = [(int(a), nm) for a, _, nm, _ in re.findall(r'"\{v\[(\d+):(\d+)\]\}"\((\w+)\[(\d)\]\)', fn)]
+    return lines, [a for a, nm in ins if nm == "x2"], [a for a, nm in ins if nm == "y2"]
+
+
+def test_generated_mixed_addition_and_window_on_the_cpu():
+    """jac_madd_asm and jac_window_asm (n doublings + the addition under a narrowed EXEC) through the interpreter:
+    generic inputs against the textbook formulas, cold paths, and the three exceptional inputs -- Z, x2 or H with a first
+    coefficient = 0 mod p -- which must leave the point untouched and report 0"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_jac_asm as gj
+    txt = open(JAC_INC).read()
+    rnd = random.Random(31)
+
+    def elem(kind):
+        if kind == "hi":
+            return [(0xFFFFFFFF << 32) | rnd.randrange(2, 2**32) for _ in range(6)]
+        if kind == "max":
+            return [2**64 - 1] * 6
+        if kind == "edge":
+            return [rnd.choice([P - 1, P + 1, 2**64 - 1, 2**32 - 1, 2**32, 2**64 - 2**32, 2**64 - 2**31, 2**63, 1]) for _ in range(6)]
+        return [rnd.randrange(1, 2**64) for _ in range(6)]
+
+    def run(lines, x2r, y2r, pt, q, env):
+        lane = ai.Lane(dict(env, **{"%[ok]": 7}))
+        for regs, val in zip((gj.XR, gj.YR, gj.ZR, x2r, y2r), list(pt) + list(q)):
+            for j in range(6):
+                lane.v[regs[j]], lane.v[regs[j] + 1] = val[j] & M32, val[j] >> 32
+        lane.run(lines)
+        assert getattr(lane, "exec_bit", 1) == 1
+        return [[(lane.v[r] | (lane.v[r + 1] << 32)) % P for r in regs] for regs in (gj.XR, gj.YR, gj.ZR)], lane.env["%[ok]"]
+
+    lines, x2r, y2r = _asm_fn(txt, "jac_madd_asm")
+    generic = 0
+    for kind in ["rand"] * 4 + ["edge"] * 6 + ["max", "hi", "hi", "hi"]:
+        pt, q = [elem(kind) for _ in range(3)], [elem(kind) for _ in range(2)]
+        got, ok = run(lines, x2r, y2r, pt, q, {})
+        want, H = _jac_madd_model(*pt, *q)
+        if pt[2][0] % P == 0 or q[0][0] % P == 0 or H[0] == 0:
+            assert ok == 0 and got == [[c % P for c in v] for v in pt]
+        else:
+            generic += 1
+            assert ok == 1 and got == want, kind
+    assert generic >= 10
+    for case in range(6):        # exceptional inputs
+        pt, q = [elem("rand") for _ in range(3)], [elem("rand") for _ in range(2)]
+        if case < 2:
+            pt[2][0] = (0, P)[case]
+        elif case < 4:
+            q[0][0] = (0, P)[case - 2]
+        else:
+            u = _f6_mulmod(q[0], _f6_mulmod(pt[2], pt[2]))
+            pt[0][0] = u[0] if case == 4 or u[0] + P >= 2**64 else u[0] + P
+        got, ok = run(lines, x2r, y2r, pt, q, {})
+        assert ok == 0 and got == [[c % P for c in v] for v in pt], case
+    lines, x2r, y2r = _asm_fn(txt, "jac_window_asm")
+    for kind in ["rand", "rand", "hi", "max"]:
+        for act in (0, 5):
+            for n in (1, 4):
+                pt, q = [elem(kind) for _ in range(3)], [elem(kind) for _ in range(2)]
+                got, ok = run(lines, x2r, y2r, pt, q, {"%[act]": act, "%[n]": n})
+                want = pt
+                for _ in range(n):
+                    want = [list(v) for v in _jac_dbl_model(*want)]
+                if act:
+                    w2, H = _jac_madd_model(*want, *q)
+                    if want[2][0] == 0 or q[0][0] % P == 0 or H[0] == 0:
+                        assert ok == 0 and got == want
+                        continue
+                    want = w2
+                assert ok == 1 and got == want, (kind, act, n)
+
+
 def test_doubling_prescale_sites_fast_and_cold():
     """one pre-scaling site in isolation (2a, c a, 2 c a): the short forms and, for operands that trip the guard, the
     exact cold forms"""
@@ -237,23 +328,29 @@ def test_doubling_prescale_sites_fast_and_cold():
 def test_doubling_asm_declares_its_registers_and_kernels_leave_room():
     """every VGPR / SGPR the doubling names is pinned or on the clobber list, SCC and VCC are declared, and every
     kernel that inlines it is built for at most two waves per SIMD (the block owns registers up to v255)"""
-    lines, txt = _jac_lines()
-    clob = set(re.findall(r'"(\w+)"', txt.split("\n        : [n]")[1]))
-    pinned = set()
-    for lo, hi in re.findall(r'"\+\{v\[(\d+):(\d+)\]\}"', txt):
-        pinned.update(range(int(lo), int(hi) + 1))
-    body = "\n".join(lines)
-    for reg in set(re.findall(r"\bv(\d+)\b", body)):
-        assert "v" + reg in clob or int(reg) in pinned, reg
-    for lo, hi in set(re.findall(r"\bv\[(\d+):(\d+)\]", body)):
-        assert int(lo) % 2 == 0 and all("v%d" % r in clob or r in pinned for r in range(int(lo), int(hi) + 1)), lo
-    for lo, hi in set(re.findall(r"\bs\[(\d+):(\d+)\]", body)):
-        assert all("s%d" % r in clob for r in range(int(lo), int(hi) + 1)), lo
-    assert {"scc", "vcc", "s20"} <= clob
+    _, whole = _jac_lines()
+    fns = re.findall(r"SSA_DEV \w+ (\w+)\(.*?asm volatile\(\n(.*?)\n        : (.*?)\);\n", whole, re.S)
+    assert [f[0] for f in fns] == ["jac_dbl_n_asm", "jac_madd_asm", "jac_window_asm"]
+    for name, body, tail in fns:
+        clob = set(re.findall(r'"(\w+)"', tail.split("\n        : ")[-1]))
+        pinned = set()
+        for lo, hi in re.findall(r'"\+?\{v\[(\d+):(\d+)\]\}"', tail):
+            pinned.update(range(int(lo), int(hi) + 1))
+        assert not (pinned & set(int(c[1:]) for c in clob if re.match(r"v\d+$", c))), name
+        for reg in set(re.findall(r"\bv(\d+)\b", body)):
+            assert "v" + reg in clob or int(reg) in pinned, (name, reg)
+        for lo, hi in set(re.findall(r"\bv\[(\d+):(\d+)\]", body)):
+            assert int(lo) % 2 == 0 and all("v%d" % r in clob or r in pinned for r in range(int(lo), int(hi) + 1)), (name, lo)
+        for lo, hi in set(re.findall(r"\bs\[(\d+):(\d+)\]", body)):
+            assert all("s%d" % r in clob for r in range(int(lo), int(hi) + 1)), (name, lo)
+        assert {"scc", "vcc"} <= clob and ("s20" in clob or "s20" not in body), name
+        if "exec" in body:       # EXEC is narrowed and restored inside the statement
+            assert body.count("s_and_saveexec_b64") == 1 and "s_mov_b64 exec, s[22:23]" in body
     src = open(os.path.join(os.path.dirname(INC), "ssa_kernels.hpp")).read()
     for m in re.finditer(r"__global__ void\s*(__launch_bounds__\(([^)]*)\))?[^{;]*?\b(ssa_k_\w+)\(.*?\n}\n", src, re.S):
-        if "mul_ptab(" in m.group(0) or "jac_dbl_n(" in m.group(0):
-            assert m.group(2) and m.group(2).replace(" ", "").endswith(",2"), m.group(3)
+        if re.search(r"mul_ptab\(|jac_dbl_n\(|add_base_mul\(|jac_madd_fast\(", m.group(0)):
+            # at most 256 threads per block: 256 VGPRs per lane stay allocatable (no bound = 1024 threads = 128 VGPRs)
+            assert m.group(2) and int(m.group(2).split(",")[0]) <= 256, m.group(3)
 
 
 def test_generated_file_is_up_to_date():

@@ -59,14 +59,16 @@ THRESH = "0xffffff00"
 
 
 class Gen:
-    def __init__(self):
+    def __init__(self, n_slots=4, n_pb=23, n_pinned_in=0, tag=""):
         self.al = Alloc()
+        self.tag = tag          # label prefix: two generators' code may share one asm statement
         self.main = []          # the loop body
         self.cold = []          # cold paths, after the loop
         self.nsite = 0
         a = self.al
-        self.S = [a.fp6() for _ in range(4)]          # Fp6 temporaries
-        self.PB = [a.pair() for _ in range(23)]       # pre-scaled operands
+        self.IN = [a.free.pop() for _ in range(n_pinned_in)][::-1]    # further pinned operands (highest free pairs)
+        self.S = [a.fp6() for _ in range(n_slots)]    # Fp6 temporaries
+        self.PB = [a.pair() for _ in range(n_pb)]     # pre-scaled operands
         self.MASK = a.pair()                          # (mask, 0)
         self.Q = [a.pair(), a.pair()]                 # (0, low word of c * a_hi)
         self.T = [a.pair(), a.pair()]                 # c * a_lo + Q
@@ -107,9 +109,9 @@ class Gen:
         for dst, sp in dbl_of:
             body += self._dbl(dst, sp)
         out += body
-        out += ["v_cmp_le_u32 vcc, %s, v%d" % (THRESH, self.G), "s_cbranch_vccnz L_cold%d_%%=" % site, "L_cont%d_%%=:" % site]
+        out += ["v_cmp_le_u32 vcc, %s, v%d" % (THRESH, self.G), "s_cbranch_vccnz L_%scold%d_%%=" % (self.tag, site), "L_%scont%d_%%=:" % (self.tag, site)]
         # cold path
-        cold = ["L_cold%d_%%=:" % site]
+        cold = ["L_%scold%d_%%=:" % (self.tag, site)]
         for _, j in dbl:
             cold += self._canon(src[j])
         for dst, j, c in mulc:
@@ -117,7 +119,7 @@ class Gen:
         for _, sp in dbl_of:          # an exact multiple may have any high word: canonicalise before the short doubling
             cold += self._canon(sp)
         cold += body
-        cold += ["s_branch L_cont%d_%%=" % site]
+        cold += ["s_branch L_%scont%d_%%=" % (self.tag, site)]
         self.cold += cold
 
     def _max3(self, first, a, b):
@@ -174,155 +176,234 @@ class Gen:
             return "v%d" % (m[nm] + (1 if half == "h" else 0))
         self.main += [re.sub(r"%\[(\w+?)([lh])\]", sub, ln) for ln in lines]
 
-    # ---- 2a - b, coefficient-wise, in place of a (one guard: the second borrow needs b's high word all ones) ----
-    def dbl_sub(self, a, b):
+    # ---- dst = (2)a - b coefficient-wise (a = None: -b); one guard: the doubling needs a's high word below all ones,
+    # the second borrow of the subtraction b's ----
+    def lin_sub(self, dst, a, b, dbl_a=False):
         site = self.nsite
         self.nsite += 1
         out = self.main
-        words = ["v%d" % (a[j] + 1) for j in range(6)] + ["v%d" % (b[j] + 1) for j in range(6)]
-        for i in range(0, 12, 2):
+        words = ["v%d" % (b[j] + 1) for j in range(6)]
+        if a is not None and dbl_a:
+            words += ["v%d" % (a[j] + 1) for j in range(6)]
+        for i in range(0, len(words), 2):
             out += [self._max3(i == 0, words[i], words[i + 1])]
         body = []
         carr = ["s[0:1]", "s[2:3]", "s[4:5]"]
+        msk = [self.UH[0], self.UH[1], self.TMP]
         for g in range(2):
             js = range(3 * g, 3 * g + 3)
+            src = {}
             for j in js:
-                body += self._dbl(a[j], a[j])
+                if a is None:
+                    src[j] = ("0", "0")
+                elif dbl_a:
+                    body += self._dbl(dst[j], a[j])
+                    src[j] = ("v%d" % dst[j], "v%d" % (dst[j] + 1))
+                else:
+                    src[j] = ("v%d" % a[j], "v%d" % (a[j] + 1))
             for j in js:
-                body += ["v_sub_co_u32 v%d, %s, v%d, v%d" % (a[j], carr[j % 3], a[j], b[j])]
+                body += ["v_sub_co_u32 v%d, %s, %s, v%d" % (dst[j], carr[j % 3], src[j][0], b[j])]
             for j in js:
-                body += ["v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (a[j] + 1, carr[j % 3], a[j] + 1, b[j] + 1, carr[j % 3])]
+                body += ["v_subb_co_u32 v%d, %s, %s, v%d, %s" % (dst[j] + 1, carr[j % 3], src[j][1], b[j] + 1, carr[j % 3])]
             # borrow: - EPS = + 1 - 2^32
             for j in js:
-                body += ["v_cndmask_b32 v%d, 0, -1, %s" % (self.UH[0] if j % 3 == 0 else self.UH[1] if j % 3 == 1 else self.TMP, carr[j % 3])]
+                body += ["v_cndmask_b32 v%d, 0, -1, %s" % (msk[j % 3], carr[j % 3])]
             for j in js:
-                body += ["v_addc_co_u32 v%d, %s, v%d, 0, %s" % (a[j], carr[j % 3], a[j], carr[j % 3])]
+                body += ["v_addc_co_u32 v%d, %s, v%d, 0, %s" % (dst[j], carr[j % 3], dst[j], carr[j % 3])]
             for j in js:
-                m = self.UH[0] if j % 3 == 0 else self.UH[1] if j % 3 == 1 else self.TMP
-                body += ["v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (a[j] + 1, carr[j % 3], a[j] + 1, m, carr[j % 3])]
-        # the guard must see the operands BEFORE they are overwritten: it runs first, the cold path falls into the body
-        out += ["v_cmp_le_u32 vcc, %s, v%d" % (THRESH, self.G), "s_cbranch_vccnz L_cold%d_%%=" % site, "L_cont%d_%%=:" % site]
+                body += ["v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (dst[j] + 1, carr[j % 3], dst[j] + 1, msk[j % 3], carr[j % 3])]
+        # the guard sees the operands BEFORE they are overwritten; the cold path canonicalises them and rejoins
+        out += ["v_cmp_le_u32 vcc, %s, v%d" % (THRESH, self.G), "s_cbranch_vccnz L_%scold%d_%%=" % (self.tag, site), "L_%scont%d_%%=:" % (self.tag, site)]
         out += body
-        cold = ["L_cold%d_%%=:" % site]
+        cold = ["L_%scold%d_%%=:" % (self.tag, site)]
         for j in range(6):
-            cold += self._canon(a[j])
+            if a is not None and dbl_a:
+                cold += self._canon(a[j])
             cold += self._canon(b[j])
-        cold += ["s_branch L_cont%d_%%=" % site]
+        cold += ["s_branch L_%scont%d_%%=" % (self.tag, site)]
         self.cold += cold
+
+    def dbl_sub(self, a, b):
+        self.lin_sub(a, a, b, dbl_a=True)
+
+    # ---- x == 0 (mod p) of one loose 64-bit value, as a word that is zero exactly then ----
+    def zero_word(self, dst, a):
+        t, u = self.UH[0], self.UH[1]
+        return ["v_or_b32 v%d, v%d, v%d" % (dst, a, a + 1),            # 0 iff a == 0
+                "v_xor_b32 v%d, 1, v%d" % (t, a), "v_not_b32 v%d, v%d" % (u, a + 1),
+                "v_or_b32 v%d, v%d, v%d" % (t, t, u),                    # 0 iff a == p
+                "v_min_u32 v%d, v%d, v%d" % (dst, dst, t)]
 
 
 def names(prefix, regs, first=0):
     return {"%s%d" % (prefix, j): regs[j] for j in range(first, 6) if regs[j] is not None}
 
 
-def build():
-    gen = Gen()
+def pres(gen, src, d_from, s_from, t_from, base=0):
+    """pre-scaled operands of src in gen.PB[base..]: d[j] = 2 src[j] (j >= d_from), s[j] = 7 src[j] (j >= s_from),
+    t[j] = 14 src[j] (j >= t_from >= s_from); None = not needed.  Returns (d, s, t, next free PB index)."""
+    PB = gen.PB
+    d, s, t = [None] * 6, [None] * 6, [None] * 6
+    n = base
+    for arr, frm in ((d, d_from), (s, s_from), (t, t_from)):
+        if frm is None:
+            continue
+        for j in range(frm, 6):
+            arr[j] = PB[n]
+            n += 1
+    gen.prescale(src, [(d[j], j) for j in range(6) if d[j] is not None],
+                 [(s[j], j, 7) for j in range(6) if s[j] is not None],
+                 [(t[j], s[j]) for j in range(6) if t[j] is not None])
+    return d, s, t, n
+
+
+def sqr_regs(src, d, s, t):
+    m = names("a", src)
+    m.update(names("d", d))
+    m.update(names("s", s))
+    m.update(names("t", t))
+    return m
+
+
+def mul_regs(a, b, b7):
+    m = names("a", a)
+    m.update(names("b", b))
+    m.update(names("s", b7))
+    return m
+
+
+def build_dbl(tag=""):
+    gen = Gen(tag=tag)
     S, PB = gen.S, gen.PB
     YY, ZZ, YYYY, SH = S[0], S[1], S[2], S[3]
     M = S[0]                       # YY is dead when M is formed
-
-    def sqr_pres(src, full):
-        """2a (j = 1..5, j = 0 too when full), 7a (3..5; 1..5 when full), 14a (4, 5; 1..5 when full) in PB[0..]"""
-        d = [None] * 6
-        s = [None] * 6
-        t = [None] * 6
-        n = 0
-        for j in range(0 if full else 1, 6):
-            d[j] = PB[n]; n += 1
-        for j in range(1 if full else 3, 6):
-            s[j] = PB[n]; n += 1
-        for j in range(1 if full else 4, 6):
-            t[j] = PB[n]; n += 1
-        gen.prescale(src, [(d[j], j) for j in range(6) if d[j] is not None],
-                     [(s[j], j, 7) for j in range(6) if s[j] is not None],
-                     [(t[j], s[j]) for j in range(6) if t[j] is not None])
-        return d, s, t, n
-
-    def sqr_regs(src, d, s, t):
-        m = names("a", src)
-        m.update(names("d", d))
-        m.update(names("s", s))
-        m.update(names("t", t))
-        return m
-
     # 1. YY = Y^2
-    d, s, t, _ = sqr_pres(YR, False)
+    d, s, t, _ = pres(gen, YR, 1, 3, 4)
     gen.block(g6.sqr_terms(), sqr_regs(YR, d, s, t), YY)
     # 2. ZZ = Z^2, Z3 = Y * (2Z)   (b = 2Z, 7b = 14Z)
-    d, s, t, _ = sqr_pres(ZR, True)
+    d, s, t, _ = pres(gen, ZR, 0, 1, 1)
     gen.block(g6.sqr_terms(), sqr_regs(ZR, d, s, t), ZZ)
-    m = names("a", YR)
-    m.update(names("b", d))
-    m.update(names("s", t))
-    gen.block(g6.mul_terms(), m, ZR)
+    gen.block(g6.mul_terms(), mul_regs(YR, d, t), ZR)
     # 3. YYYY = YY^2, S' = X * (2 YY)
-    d, s, t, _ = sqr_pres(YY, True)
+    d, s, t, _ = pres(gen, YY, 0, 1, 1)
     gen.block(g6.sqr_terms(), sqr_regs(YY, d, s, t), YYYY)
-    m = names("a", XR)
-    m.update(names("b", d))
-    m.update(names("s", t))
-    gen.block(g6.mul_terms(), m, SH)
-    # 4. M = ZZ^2 + 3 X^2: the squaring's terms twice, the second time on X with 3X, 6X, 21X, 42X
-    d, s, t, n = sqr_pres(ZZ, False)
+    gen.block(g6.mul_terms(), mul_regs(XR, d, t), SH)
+    # 4. M = ZZ^2 + 3 X^2: the squaring's terms twice, the second time on X with 3X (diagonal), 6X (cross), 21X
+    #    (wrapped diagonal), 42X (wrapped cross)
+    d, s, t, n = pres(gen, ZZ, 1, 3, 4)
     x3 = [PB[n + j] for j in range(3)] + [None] * 3
     x6 = [None] + [PB[n + 3 + j] for j in range(5)]
     x21 = [None] * 3 + [PB[n + 8 + j] for j in range(3)]
     x42 = [None] * 4 + [PB[n + 11 + j] for j in range(2)]
-    # 6X = 2 (3X) needs 3X for j = 1..5 as well: 3X[3..5] live in the 21X / 42X slots' neighbours -- simply compute 6X
-    # as a constant multiple where 3X is not kept
     mulc = [(x3[j], j, 3) for j in range(3)] + [(x6[j], j, 6) for j in range(3, 6)] + [(x21[j], j, 21) for j in range(3, 6)]
     dbl_of = [(x6[j], x3[j]) for j in range(1, 3)] + [(x42[j], x21[j]) for j in range(4, 6)]
     gen.prescale(XR, [], mulc, dbl_of)
     terms = g6.sqr_terms()
-    rename = {"a": "x", "d": "e", "s": "f", "t": "g"}
-    terms2 = [[(x.replace("a", "x"), rename[y[0]] + y[1:]) for x, y in tk] for tk in terms]
+    second = {"a": "h", "d": "e", "s": "f", "t": "g"}
+    terms2 = [[("x" + x[1:], second[y[0]] + y[1:]) for x, y in tk] for tk in terms]
     m = sqr_regs(ZZ, d, s, t)
     m.update(names("x", XR))
-    # diagonal direct terms use 3X (j <= 2), cross direct 6X, diagonal wrapped 21X, cross wrapped 42X
-    m.update({"x%d" % j: XR[j] for j in range(6)})
-    m.update({"e%d" % j: x6[j] for j in range(1, 6)})
-    m.update({"f%d" % j: x21[j] for j in range(3, 6)})
-    m.update({"g%d" % j: x42[j] for j in range(4, 6)})
-    # the diagonal direct term of sqr_terms is (a_i, a_i): on X it must be (x_i, 3 x_i)
-    terms2 = [[(x, ("h" + y[1:]) if y[0] == "x" else y) for x, y in tk] for tk in terms2]
-    m.update({"h%d" % j: x3[j] for j in range(3)})
+    m.update(names("h", x3))
+    m.update(names("e", x6))
+    m.update(names("f", x21))
+    m.update(names("g", x42))
     gen.block([a + b for a, b in zip(terms, terms2)], m, M)
     # 5. X3 = M^2 - 4 S'  (into X), with 7M for all j: shared with the product of step 6
-    dM = [None] + [PB[j] for j in range(5)]
-    sM = [None] + [PB[5 + j] for j in range(5)]
-    tM = [None] * 4 + [PB[10], PB[11]]
-    gen.prescale(M, [(dM[j], j) for j in range(1, 6)], [(sM[j], j, 7) for j in range(1, 6)], [(tM[j], sM[j]) for j in range(4, 6)])
+    dM, sM, tM, _ = pres(gen, M, 1, 1, 4)
     gen.block(g6.sqr_terms(), sqr_regs(M, dM, sM, tM), XR, extras=[(-1, 4, "x")], extra_regs={"x": SH})
     # 6. W = 2 S' - X3 (in place of S'), Y3 = W * M - 8 YYYY  (into Y)
     gen.dbl_sub(SH, XR)
-    m = names("a", SH)
-    m.update(names("b", M))
-    m.update(names("s", sM))
-    gen.block(g6.mul_terms(), m, YR, extras=[(-1, 8, "x")], extra_regs={"x": YYYY})
+    gen.block(g6.mul_terms(), mul_regs(SH, M, sM), YR, extras=[(-1, 8, "x")], extra_regs={"x": YYYY})
     return gen
 
 
-def emit():
-    gen = build()
-    pre = ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["s_mov_b32 s20, %[n]", "L_top_%=:"]
-    post = ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%=", "s_branch L_end_%="]
-    body = pre + gen.main + post + gen.cold + ["L_end_%=:"]
+def build_madd(tag=""):
+    """(X, Y, Z) += (x2, y2), the generic path of the mixed addition (7M + 4S as 8 products + 3 squares):
+        Z1Z1 = Z^2   T = y2 Z   H = x2 Z1Z1 - X   R = T Z1Z1 - Y   HH = H^2   Z3 = Z H   HHH = HH H   V = X HH
+        X3 = R^2 - HHH - 2V      Y3 = (V - X3) R + HHH (-Y)
+    The exceptional inputs (Z == 0, (x2, y2) == (0, 0), H == 0) are NOT handled here: a necessary condition of each
+    (first coefficient zero mod p) is tested before anything is written, and the block then leaves the point untouched
+    and reports 0 -- the caller runs the compiled, exact jac_madd for that wave.  Honest inputs never get there."""
+    gen = Gen(n_slots=5, n_pb=17, n_pinned_in=12, tag=tag)
+    S = gen.S
+    x2, y2 = gen.IN[0:6], gen.IN[6:12]
+    Z1Z1, T, H, R, HH = S[0], S[1], S[2], S[3], S[4]
+    Z3, HHH, V, NY = S[0], S[1], S[4], S[2]
+    f, w = gen.G, gen.TMP
+    # exceptional inputs, part 1 (G doubles as the flag word here; the guards below rewrite it afterwards)
+    gen.main += gen.zero_word(w, ZR[0])
+    gen.main += ["v_mov_b32 v%d, v%d" % (gen.MASK, w)]
+    gen.main += gen.zero_word(w, x2[0])
+    gen.main += ["v_min_u32 v%d, v%d, v%d" % (gen.MASK, gen.MASK, w), "v_cmp_eq_u32 vcc, 0, v%d" % gen.MASK,
+                 "s_cbranch_vccnz L_bail_%="]
+    # 1. Z1Z1 = Z^2, T = y2 * Z
+    d, s, t, _ = pres(gen, ZR, 1, 1, 4)
+    gen.block(g6.sqr_terms(), sqr_regs(ZR, d, s, t), Z1Z1)
+    gen.block(g6.mul_terms(), mul_regs(y2, ZR, s), T)
+    # 2. H = x2 Z1Z1 - X, R = T Z1Z1 - Y
+    _, s, _, _ = pres(gen, Z1Z1, None, 1, None)
+    gen.block(g6.mul_terms(), mul_regs(x2, Z1Z1, s), H, extras=[(-1, 1, "x")], extra_regs={"x": XR})
+    gen.block(g6.mul_terms(), mul_regs(T, Z1Z1, s), R, extras=[(-1, 1, "x")], extra_regs={"x": YR})
+    # exceptional inputs, part 2: H == 0 (P == +-Q)
+    gen.main += gen.zero_word(w, H[0])
+    gen.main += ["v_cmp_eq_u32 vcc, 0, v%d" % w, "s_cbranch_vccnz L_bail_%="]
+    # 3. HH = H^2, Z3 = Z H, HHH = HH H
+    d, s, t, _ = pres(gen, H, 1, 1, 4)
+    gen.block(g6.sqr_terms(), sqr_regs(H, d, s, t), HH)
+    gen.block(g6.mul_terms(), mul_regs(ZR, H, s), Z3)
+    gen.block(g6.mul_terms(), mul_regs(HH, H, s), HHH)
+    # 4. V = X HH (in place of HH: the product reads b = HH, so it goes to H's slot first)
+    _, s, _, _ = pres(gen, HH, None, 1, None)
+    gen.block(g6.mul_terms(), mul_regs(XR, HH, s), H)
+    V = H
+    # 5. X3 = R^2 - HHH - 2V  (into X)
+    d, sR, t, n = pres(gen, R, 1, 1, 4)
+    gen.block(g6.sqr_terms(), sqr_regs(R, d, sR, t), XR, extras=[(-1, 1, "x"), (-1, 2, "y")], extra_regs={"x": HHH, "y": V})
+    # 6. W = V - X3 (in place), NY = -Y, Y3 = W R + HHH NY  (into Y)
+    gen.lin_sub(V, V, XR)
+    NY = S[4]
+    gen.lin_sub(NY, None, YR)
+    _, sN, _, _ = pres(gen, NY, None, 1, None, base=n)
+    m = mul_regs(V, R, sR)
+    m.update(names("c", HHH))
+    m.update(names("e", NY))
+    m.update(names("t", sN))
+    gen.block(g6.mul2_terms(), m, YR)
+    # 7. Z3 into Z
+    for j in range(6):
+        gen.main += ["v_mov_b32 v%d, v%d" % (ZR[j], Z3[j]), "v_mov_b32 v%d, v%d" % (ZR[j] + 1, Z3[j] + 1)]
+    return gen
+
+
+def check_and_stats(gen, body, pinned):
     used = set(gen.al.used) | set(g6.POOL[:g6.N_FIXED + 4])
     for ln in body:
         for r in re.findall(r"\bv(\d+)\b", ln):
-            assert int(r) in used or int(r) in _pin_regs, ln
+            assert int(r) in used or int(r) in pinned, ln
         for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", ln):
             assert int(lo) % 2 == 0 and int(hi) == int(lo) + 1, ln
-            assert int(lo) in used or int(lo) in _pin_regs, ln
+            assert int(lo) in used or int(lo) in pinned, ln
     n_valu = sum(1 for ln in gen.main if ln.startswith("v_"))
     n_mad = sum(1 for ln in gen.main if ln.startswith("v_mad"))
     n_nop = sum(1 for ln in gen.main if ln.startswith("s_nop"))
-    out = ["// generated by tools/gen_jac_asm.py -- do not edit (see that file for the design notes)",
-           "// (X, Y, Z) <- [2^n](X, Y, Z), n >= 1, Jacobian, a = 1 (loose in / loose out; Z == 0 stays Z == 0).",
-           "// One doubling: %d VALU instructions (%d multiplies) + %d s_nop on the hot path." % (n_valu, n_mad, n_nop),
-           "SSA_DEV void jac_dbl_n_asm(u64 (&X)[6], u64 (&Y)[6], u64 (&Z)[6], u32 n) {", "    asm volatile("]
+    return used, n_valu, n_mad, n_nop
+
+
+def asm_lines(out, body):
     for i, ln in enumerate(body):
         out.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(body) else ""))
+
+
+def emit_dbl():
+    gen = build_dbl()
+    pre = ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["s_mov_b32 s20, %[n]", "L_top_%=:"]
+    post = ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%=", "s_branch L_end_%="]
+    body = pre + gen.main + post + gen.cold + ["L_end_%=:"]
+    used, n_valu, n_mad, n_nop = check_and_stats(gen, body, _pin_regs)
+    out = ["// (X, Y, Z) <- [2^n](X, Y, Z), n >= 1, Jacobian, a = 1 (loose in / loose out; Z == 0 stays Z == 0).",
+           "// One doubling: %d VALU instructions (%d multiplies) + %d s_nop on the hot path." % (n_valu, n_mad, n_nop),
+           "SSA_DEV void jac_dbl_n_asm(u64 (&X)[6], u64 (&Y)[6], u64 (&Z)[6], u32 n) {", "    asm volatile("]
+    asm_lines(out, body)
     ops = []
     for nm, regs in (("X", XR), ("Y", YR), ("Z", ZR)):
         for j in range(6):
@@ -337,8 +418,81 @@ def emit():
     return out
 
 
+def emit_madd():
+    gen = build_madd()
+    pinned = _pin_regs | set(r for p in gen.IN for r in (p, p + 1))
+    pre = ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["v_mov_b32 %[ok], 1"]
+    post = ["s_branch L_end_%="]
+    bail = ["L_bail_%=:", "v_mov_b32 %[ok], 0"]
+    body = pre + gen.main + post + gen.cold + bail + ["L_end_%=:"]
+    used, n_valu, n_mad, n_nop = check_and_stats(gen, [ln for ln in body if "%[ok]" not in ln], pinned)
+    out = ["// (X, Y, Z) += (x2, y2): the generic path of the mixed addition; returns 0 with the point untouched when an",
+           "// exceptional input is possible (Z, x2 or H with a first coefficient = 0 mod p): the caller then runs jac_madd.",
+           "// %d VALU instructions (%d multiplies) + %d s_nop on the hot path." % (n_valu, n_mad, n_nop),
+           "SSA_DEV u32 jac_madd_asm(u64 (&X)[6], u64 (&Y)[6], u64 (&Z)[6], const u64 (&x2)[6], const u64 (&y2)[6]) {",
+           "    u32 ok;", "    asm volatile("]
+    asm_lines(out, body)
+    ops = ['[ok] "=&v"(ok)']
+    for nm, regs in (("X", XR), ("Y", YR), ("Z", ZR)):
+        for j in range(6):
+            ops.append('"+{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
+    out.append("        : " + ",\n          ".join(ops))
+    ins = []
+    for nm, regs in (("x2", gen.IN[0:6]), ("y2", gen.IN[6:12])):
+        for j in range(6):
+            ins.append('"{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
+    out.append("        : " + ",\n          ".join(ins))
+    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(21)] + ['"vcc"', '"scc"']
+    out.append("        : " + ", ".join(clob) + ");")
+    out += ["    return ok;", "}"]
+    print("mixed addition: %d VALU (%d multiplies), %d s_nop; %d fixed VGPRs + 60 pinned; %d cold-path lines"
+          % (n_valu, n_mad, n_nop, len(used), len(gen.cold)))
+    return out
+
+
+def emit_window():
+    """n doublings, then the mixed addition on the lanes whose `act` word is non-zero (EXEC narrowed inside the
+    statement): one statement per ladder window, the point never leaves its registers in between"""
+    gd, gm = build_dbl("d"), build_madd("m")
+    in_regs = set(r for p in gm.IN for r in (p, p + 1))
+    assert not (set(gd.al.used) & in_regs)
+    pinned = _pin_regs | in_regs
+    pre = ["v_mov_b32 v%d, 0" % r for r in gd.zero_regs] + ["v_mov_b32 %[ok], 1", "s_mov_b32 s20, %[n]", "L_top_%=:"]
+    loop_end = ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%="]
+    narrow = ["v_cmp_ne_u32 vcc, 0, %[act]", "s_and_saveexec_b64 s[22:23], vcc", "s_cbranch_execz L_skip_%="]
+    zero_m = ["v_mov_b32 v%d, 0" % r for r in gm.zero_regs if r not in gd.zero_regs]
+    skip = ["L_skip_%=:", "s_mov_b64 exec, s[22:23]", "s_branch L_end_%="]
+    bail = ["L_bail_%=:", "v_mov_b32 %[ok], 0", "s_branch L_skip_%="]
+    body = pre + gd.main + loop_end + narrow + zero_m + gm.main + skip + gd.cold + gm.cold + bail + ["L_end_%=:"]
+    plain = [ln for ln in body if "%[" not in ln]
+    used_d, nv_d, nm_d, nn_d = check_and_stats(gd, [ln for ln in plain], pinned | set(gm.al.used) | set(g6.POOL[:g6.N_FIXED + 4]))
+    used = used_d | set(gm.al.used)
+    out = ["// n doublings, then (X, Y, Z) += (x2, y2) on the lanes with act != 0: one ladder window as ONE statement.",
+           "// Returns 0 when the addition met a possible exceptional input on some lane (the doublings are done, the addition",
+           "// is not: the caller runs the compiled jac_madd on the lanes with act != 0).",
+           "SSA_DEV u32 jac_window_asm(u64 (&X)[6], u64 (&Y)[6], u64 (&Z)[6], const u64 (&x2)[6], const u64 (&y2)[6], u32 act, u32 n) {",
+           "    u32 ok;", "    asm volatile("]
+    asm_lines(out, body)
+    ops = ['[ok] "=&v"(ok)']
+    for nm, regs in (("X", XR), ("Y", YR), ("Z", ZR)):
+        for j in range(6):
+            ops.append('"+{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
+    out.append("        : " + ",\n          ".join(ops))
+    ins = ['[act] "v"(act)', '[n] "s"(n)']
+    for nm, regs in (("x2", gm.IN[0:6]), ("y2", gm.IN[6:12])):
+        for j in range(6):
+            ins.append('"{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
+    out.append("        : " + ",\n          ".join(ins))
+    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(24)] + ['"vcc"', '"scc"']
+    out.append("        : " + ", ".join(clob) + ");")
+    out += ["    return ok;", "}"]
+    print("window: %d fixed VGPRs + 60 pinned" % len(used))
+    return out
+
+
 def main():
-    out = emit()
+    out = ["// generated by tools/gen_jac_asm.py -- do not edit (see that file for the design notes)"] + emit_dbl() + [""] + emit_madd() \
+        + [""] + emit_window()
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc", "jac_asm.inc")
     with open(path, "w") as fh:
         fh.write("\n".join(out) + "\n")
