@@ -177,7 +177,7 @@ msm_k_buckets(const u64 *__restrict__ points, const u32 *__restrict__ vals, cons
 #pragma unroll 1
         for (u32 p = lo; p < hi; p++) {
             const aff q = ld_aff(points + 12 * (size_t)vals[p]);
-            acc = jac_madd(acc, q);
+            acc = jac_madd_fast(acc, q);      // asm block; identity / equal points fall back to the exact addition
         }
     }
     st_jac(bsum + 18 * t, acc);
