@@ -258,7 +258,12 @@ int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, const uint8_t 
  *     7 = the cooperative (one wave per point) operations: a = (x, y, inf, mode), b = (x, y, inf);
  *         mode 0 mixed addition, 1 general addition of two scaled Jacobian points, 2 doubling of a
  *     8..14 = products fused with linear terms, a = (u, v) 12 felts, b = (x, y) 12 felts -> 6 felts:
- *         8 u^2 - x - y, 9 u^2 + 3x, 10 u^2 - 4x, 11 u*v - 8x, 12 u*v - x, 13 u^2 - x - 2y, 14 u*v + x*y */
+ *         8 u^2 - x - y, 9 u^2 + 3x, 10 u^2 - 4x, 11 u*v - 8x, 12 u*v - x, 13 u^2 - x - 2y, 14 u*v + x*y
+ *     15..17 = the generated point operations of the ladder on RAW loose limbs (any 64-bit values, nothing is
+ *         canonicalised on the way in or out): a = X, Y, Z (18 words), a[18] = act, a[19] = n; b = x2, y2 (12 words)
+ *         -> X, Y, Z (18 words) + out[18] = flag.  15 one ladder window (n doublings, then the mixed addition where
+ *         act != 0; flag 0 = the addition met a possible exceptional input and was left to the caller),
+ *         16 mixed addition with its exact fallback, 17 n doublings */
 int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                     size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride);
 /* n_blocks 64-byte blocks of the ChaCha20 keystream the MSM coefficients come from (RFC 8439 known answers) */

@@ -818,7 +818,7 @@ extern "C" int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, con
 // ------------------------------------------------------------------ probes
 extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                                size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {
-    if (!ctx || !a || !out || n == 0 || op < 0 || op > 14) return SSA_ERR_ARG;
+    if (!ctx || !a || !out || n == 0 || op < 0 || op > 17) return SSA_ERR_ARG;
     if ((op == 0 || op == 3 || op == 4 || op == 5 || op >= 7) && !b) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const void *da, *db = nullptr;
@@ -830,9 +830,9 @@ extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const ui
     if (op == 7) {
         hipLaunchKernelGGL(ssa_k_debug_coop, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const u64 *)da,
                            (const u64 *)db, n, a_stride, b_stride, (u64 *)ctx->st_status.p, out_stride);
-    } else if (op == 4) {
+    } else if (op == 4 || op >= 15) {
         if (ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
-        hipLaunchKernelGGL(ssa_k_debug_mul, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const u64 *)da,
+        hipLaunchKernelGGL(ssa_k_debug_mul, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, op, (const u64 *)da,
                            (const u64 *)db, n, a_stride, b_stride, (u64 *)ctx->ws_tab.p,
                            (u64 *)ctx->st_status.p, out_stride);
     } else {

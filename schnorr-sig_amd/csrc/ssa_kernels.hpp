@@ -1000,13 +1000,38 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
 // [k]P with the production table code path (op 4): a = k (4 u64), b = P (12 u64 + inf)
 #ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256, 2)      // the asm doubling owns VGPRs up to v255: two waves per SIMD at most
-ssa_k_debug_mul(const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
+ssa_k_debug_mul(int op, const u64 *__restrict__ a, const u64 *__restrict__ b, size_t n,
                                 size_t as, size_t bs, u64 *__restrict__ ws_tab,
                                 u64 *__restrict__ out, size_t os) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 *pa = a + i * as, *pb = b + i * bs;
     u64 *po = out + i * os;
+    if (op >= 15) {
+        // the generated point operations on RAW loose limbs (any 64-bit values): a = X, Y, Z (18 u64), a[18] = act,
+        // a[19] = n; b = x2, y2 (12 u64) -> X, Y, Z as they come out (not canonicalised) + out[18] = the statement's flag
+        //   15: one ladder window (n doublings, then the addition where act != 0)   16: jac_madd_fast   17: jac_dbl_n
+        jac p;
+        aff q;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            p.X.c[j] = pa[j]; p.Y.c[j] = pa[6 + j]; p.Z.c[j] = pa[12 + j];
+            q.x.c[j] = pb[j]; q.y.c[j] = pb[6 + j];
+        }
+        u32 flag = 1;
+#ifdef SSA_JAC_ASM
+        if (op == 15) flag = jac_window_asm(p.X.c, p.Y.c, p.Z.c, q.x.c, q.y.c, (u32)pa[18], (u32)pa[19]);
+        else
+#endif
+        if (op == 16) p = jac_madd_fast(p, q);
+        else p = jac_dbl_n(p, (u32)pa[19]);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            po[j] = p.X.c[j]; po[6 + j] = p.Y.c[j]; po[12 + j] = p.Z.c[j];
+        }
+        po[18] = flag;
+        return;
+    }
     sc256 k;
 #pragma unroll
     for (int j = 0; j < 4; j++) k.w[j] = pa[j];

@@ -474,3 +474,94 @@ def test_fused_product_blocks(engine):
             u, v = [int(t) for t in a[i, :6]], [int(t) for t in a[i, 6:]]
             x, y = [int(t) for t in b[i, :6]], [int(t) for t in b[i, 6:]]
             assert [int(t) for t in got[i]] == model(u, v, x, y), (op, i)
+
+
+# ---------------------------------------------------------------- generated point operations on raw limbs
+def test_generated_point_operations_on_raw_limbs(engine):
+    """The asm statements of the ladder (jac_asm.inc: n doublings, mixed addition, one whole window) on the GPU with
+    arbitrary loose 64-bit limbs, against the textbook formulas on plain integers.  Rows whose high words are all ones,
+    or whose 7x / 3x / 21x multiples land next to 2^32, force every guarded pre-scaling site into its cold path on
+    real hardware; rows with Z, x2 or H = 0 (mod p) in the first coefficient take the exceptional exit (window: flag 0,
+    doublings done, addition left to the caller; jac_madd_fast: the exact compiled addition)."""
+    rng = np.random.default_rng(77)
+
+    def mulmod(u, v):
+        t = [0] * 12
+        for i, x in enumerate(u):
+            for j, y in enumerate(v):
+                t[i + j] += x * y
+        return [(t[k] + 7 * t[k + 6]) % P for k in range(6)]
+
+    sub = lambda u, v: [(a - b) % P for a, b in zip(u, v)]
+    add = lambda u, v: [(a + b) % P for a, b in zip(u, v)]
+    sc = lambda c, u: [c * a % P for a in u]
+
+    def dbl(X, Y, Z):
+        XX, YY, ZZ = mulmod(X, X), mulmod(Y, Y), mulmod(Z, Z)
+        YYYY = mulmod(YY, YY)
+        t = add(X, YY)
+        S = sc(2, sub(sub(mulmod(t, t), XX), YYYY))
+        M = add(sc(3, XX), mulmod(ZZ, ZZ))
+        X3 = sub(mulmod(M, M), sc(2, S))
+        return X3, sub(mulmod(M, sub(S, X3)), sc(8, YYYY)), sc(2, mulmod(Y, Z))
+
+    def madd(X, Y, Z, x2, y2):
+        ZZ = mulmod(Z, Z)
+        H, R = sub(mulmod(x2, ZZ), X), sub(mulmod(mulmod(y2, Z), ZZ), Y)
+        HH = mulmod(H, H)
+        HHH, V = mulmod(H, HH), mulmod(X, HH)
+        X3 = sub(sub(mulmod(R, R), HHH), sc(2, V))
+        return (X3, sub(mulmod(R, sub(V, X3)), mulmod(Y, HHH)), mulmod(Z, H)), H
+
+    n = 1536
+    a = rng.integers(1, 2**64, size=(n, 20), dtype=np.uint64)
+    b = rng.integers(1, 2**64, size=(n, 12), dtype=np.uint64)
+    hi = np.uint64(0xFFFFFFFF) << np.uint64(32)
+    a[256:512, :18] |= hi                      # high words all ones: the doublings' guards
+    b[384:640] |= hi
+    for r in range(512, 768):                  # c * a_hi within a few units of 2^32: the multiples' guards
+        for c_ in range(18):
+            c = (3, 7, 21)[(r + c_) % 3]
+            h = (2**32 - int(rng.integers(1, 64))) * pow(c, -1, 2**32) % 2**32
+            a[r, c_] = np.uint64((h << 32) | int(rng.integers(0, 2**32)))
+    a[768:800, :18] = np.uint64(2**64 - 1)
+    a[:, 18] = rng.integers(0, 2, size=n) * rng.integers(1, 9, size=n)        # act: zero on about half the rows
+    a[:, 19] = 3                                                             # n doublings (uniform per launch)
+    # exceptional inputs of the addition (first coefficient = 0 mod p) in a wave of their own: the statement's flag is
+    # per wave (one lane with a possible exceptional input sends all its active lanes to the caller's exact addition)
+    a[832:848, 12] = 0
+    a[848:864, 12] = np.uint64(P)
+    b[864:880, 0] = 0
+    b[880:896, 0] = np.uint64(P)
+    a[832:896, 18] = 1
+    check = list(range(0, 256, 5)) + list(range(256, 900, 3)) + list(range(900, n, 11))
+    got15 = engine.debug_arith(15, a, b, 19)
+    got16 = engine.debug_arith(16, a, b, 19)
+    got17 = engine.debug_arith(17, a, b, 19)
+    n_cold_like = n_bail = 0
+    for i in check:
+        pt = [[int(t) for t in a[i, 6 * k:6 * k + 6]] for k in range(3)]
+        q = [[int(t) for t in b[i, 6 * k:6 * k + 6]] for k in range(2)]
+        act, nd = int(a[i, 18]), int(a[i, 19])
+        d = pt
+        for _ in range(nd):
+            d = [list(v) for v in dbl(*d)]
+        red = lambda row: [[int(t) % P for t in row[6 * k:6 * k + 6]] for k in range(3)]
+        assert red(got17[i]) == d, ("dbl_n", i)
+        want = d
+        if act:
+            m, H = madd(*d, *q)
+            if 832 <= i < 896 or d[2][0] == 0 or q[0][0] % P == 0 or H[0] == 0:
+                n_bail += 1        # (rows 864..895 have x2 = 0 in the first coefficient: their whole wave is handed back)
+                assert int(got15[i, 18]) == 0 and red(got15[i]) == d, ("window exceptional", i)
+                want = None
+            else:
+                want = [list(v) for v in m]
+        if want is not None:
+            assert int(got15[i, 18]) == 1 and red(got15[i]) == want, ("window", i)
+        # the addition alone, with its exact fallback: generic rows against the formulas
+        m, H = madd(*pt, *q)
+        if not (pt[2][0] % P == 0 or q[0][0] % P == 0 or H[0] == 0):
+            assert red(got16[i]) == [list(v) for v in m], ("madd", i)
+        n_cold_like += i >= 256 and i < 800
+    assert n_bail >= 4 and n_cold_like > 100

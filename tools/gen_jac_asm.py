@@ -409,7 +409,7 @@ def emit_dbl():
         for j in range(6):
             ops.append('"+{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
     out.append("        : " + ",\n          ".join(ops))
-    out.append('        : [n] "s"(n)')
+    out.append('        : [n] "s"(__builtin_amdgcn_readfirstlane(n))      // wave-uniform by contract')
     clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(21)] + ['"vcc"', '"scc"']
     out.append("        : " + ", ".join(clob) + ");")
     out.append("}")
@@ -478,7 +478,7 @@ def emit_window():
         for j in range(6):
             ops.append('"+{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
     out.append("        : " + ",\n          ".join(ops))
-    ins = ['[act] "v"(act)', '[n] "s"(n)']
+    ins = ['[act] "v"(act)', '[n] "s"(__builtin_amdgcn_readfirstlane(n))']
     for nm, regs in (("x2", gm.IN[0:6]), ("y2", gm.IN[6:12])):
         for j in range(6):
             ins.append('"{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
