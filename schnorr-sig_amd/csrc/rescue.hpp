@@ -104,12 +104,41 @@ SSA_DEV void mds_ark(const u64 *src, u64 *dst, const u64 *__restrict__ mds, cons
     }
 }
 
+// The same layer for an MDS matrix whose entries are below 2^16 (PRM_FLAG_TINY_MDS; upstream-style circulants of
+// one- and two-digit integers): the low and the high words of the state are accumulated separately,
+//   lo = ark_lo + sum v_j.lo * m_ij < 2^52,  hi = ark_hi + sum v_j.hi * m_ij < 2^52,  row = lo + 2^32 hi,
+// 24 multiply-adds chained through their 64-bit addend with NO carry bookkeeping (the general path pays a carry add
+// per multiply and a three-column fold), the round constant rides in the two opening addends, and the reduction is
+// one add, one multiply-add by EPS for bits 64.. and one wrap-around fix-up.
+SSA_DEV void mds_ark_tiny(const u64 *src, u64 *dst, const u64 *__restrict__ mds, const u64 *__restrict__ ark) {
+    u64 v[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) v[j] = src[j * RS_STRIDE];
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        const u64 *row = mds + i * 12;
+        const u64 k = ark[i];
+        u64 lo = (u64)lo32(k), hi = (u64)hi32(k);
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const u32 m = (u32)row[j];
+            lo += (u64)lo32(v[j]) * m;
+            hi += (u64)hi32(v[j]) * m;
+        }
+        // lo + 2^32 hi = (lo + 2^32 hi_l) + 2^64 hi_h;  2^64 = EPS
+        const u64 t = lo + ((u64)lo32(hi) << 32);
+        const u32 top = hi32(hi) + (t < lo ? 1u : 0u);        // < 2^21
+        dst[i * RS_STRIDE] = fp_reduce_parts(t, top, 0ull);
+    }
+}
+
 // permutation of the state in plane A (plane B is scratch); result back in plane A
-constexpr u32 PRM_FLAG_SMALL_MDS = 1u;
+constexpr u32 PRM_FLAG_SMALL_MDS = 1u, PRM_FLAG_TINY_MDS = 2u;
 
 SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ prm) {
     const u32 nr = prm->n_rounds;
     const bool small = (prm->flags & PRM_FLAG_SMALL_MDS) != 0;
+    const bool tiny = (prm->flags & PRM_FLAG_TINY_MDS) != 0;
 #pragma unroll 1
     for (u32 r = 0; r < nr; r++) {
 #pragma unroll 1
@@ -119,7 +148,8 @@ SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ pr
             A[i * RS_STRIDE] = x;
             A[(i + 6) * RS_STRIDE] = y;
         }
-        if (small) mds_ark<true>(A, B, prm->mds, prm->ark1 + 12 * r);
+        if (tiny) mds_ark_tiny(A, B, prm->mds, prm->ark1 + 12 * r);
+        else if (small) mds_ark<true>(A, B, prm->mds, prm->ark1 + 12 * r);
         else mds_ark<false>(A, B, prm->mds, prm->ark1 + 12 * r);
 #pragma unroll 1
         for (int i = 0; i < 6; i++) {
@@ -128,7 +158,8 @@ SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ pr
             B[i * RS_STRIDE] = x;
             B[(i + 6) * RS_STRIDE] = y;
         }
-        if (small) mds_ark<true>(B, A, prm->mds, prm->ark2 + 12 * r);
+        if (tiny) mds_ark_tiny(B, A, prm->mds, prm->ark2 + 12 * r);
+        else if (small) mds_ark<true>(B, A, prm->mds, prm->ark2 + 12 * r);
         else mds_ark<false>(B, A, prm->mds, prm->ark2 + 12 * r);
     }
 }

@@ -62,6 +62,9 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     bool small_mds = true;
     for (int i = 0; i < 144; i++) small_mds = small_mds && hp.mds[i] <= 0xffffffffull;
     if (small_mds) hp.flags |= PRM_FLAG_SMALL_MDS;
+    bool tiny_mds = true;      // entries below 2^16 (the usual circulant of single-digit integers): carry-free MDS rows
+    for (int i = 0; i < 144; i++) tiny_mds = tiny_mds && hp.mds[i] < 0x10000ull;
+    if (tiny_mds) hp.flags |= PRM_FLAG_TINY_MDS;
     HIP_TRY(hipSetDevice(device));
     ssa_ctx *ctx = new ssa_ctx();
     ctx->device = device;

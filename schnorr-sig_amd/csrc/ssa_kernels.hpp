@@ -819,7 +819,7 @@ SSA_DEV sc256 sc_mul_mod(const sc256 &a, const sc256 &b) {
 }
 
 #ifndef SSA_NO_KERNELS
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 ssa_k_sign(const DevParams *__restrict__ prm, const u64 *__restrict__ gtab,
            const u8 *__restrict__ sks, const u8 *__restrict__ nonces, MsgView mv, size_t n,
            u8 *__restrict__ pks_out, u8 *__restrict__ sigs_out) {

@@ -517,6 +517,9 @@ def test_alternative_parameter_blobs(oracle):
     b = bytearray(base)                                  # (3) length in state[0], rate = state[4..12]
     struct.pack_into("<IIiIII", b, 8, 7, 4, 0, 0, 4, 0)
     variants.append(bytes(b))
+    b = bytearray(base)                                  # (4) MDS entries of 17..32 bits: the 32-bit-multiplier path
+    struct.pack_into("<144Q", b, 32, *[int(v) for v in rng.integers(2**16, 2**32, size=144)])     # (the default
+    variants.append(bytes(b))                                                  # blob's entries take the carry-free one)
     for blob in variants:
         orc = Oracle(blob=blob)
         eng = ssa.Engine(0, params=blob)

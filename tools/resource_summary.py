@@ -23,15 +23,21 @@ def main():
                                    os.path.join(CSRC, unit)], stderr=subprocess.DEVNULL)
             s = open(out).read()
         print("## " + unit)
-        for m in re.finditer(r"^(_ZN3ssa\w+):.*?; codeLenInByte = (\d+).*?; NumVgprs: (\d+)\n; NumAgprs: (\d+).*?; ScratchSize: (\d+)"
-                             r".*?; LDSByteSize: (\d+).*?; Occupancy: (\d+)", s, re.S | re.M):
-            name = m.group(1)
-            if "_k_" not in name:
+        # one chunk per function label (a non-kernel function has no "Occupancy" line: a pattern spanning labels would
+        # swallow the kernel that follows it)
+        chunks = re.split(r"^(?=_ZN3ssa\w+:)", s, flags=re.M)
+        for ch in chunks:
+            m = re.match(r"(_ZN3ssa\w+):", ch)
+            if not m or "_k_" not in m.group(1):
                 continue
-            short = re.sub(r"^_ZN3ssa\d+", "", name)
+            r = re.search(r"; codeLenInByte = (\d+).*?; NumVgprs: (\d+)\n; NumAgprs: (\d+).*?; ScratchSize: (\d+)"
+                          r".*?; LDSByteSize: (\d+).*?; Occupancy: (\d+)", ch, re.S)
+            if not r:
+                continue
+            short = re.sub(r"^_ZN3ssa\d+", "", m.group(1))
             short = re.match(r"[a-z0-9_]+", short).group(0)
             print("%-28s code %7d B  vgpr %3d  agpr %3d  scratch %5d B  lds %6d B  waves/SIMD %d"
-                  % (short, int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6)), int(m.group(7))))
+                  % (short, int(r.group(1)), int(r.group(2)), int(r.group(3)), int(r.group(4)), int(r.group(5)), int(r.group(6))))
 
 
 if __name__ == "__main__":
