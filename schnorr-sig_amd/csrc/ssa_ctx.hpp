@@ -77,7 +77,7 @@ struct ssa_ctx {
     bool default_params = false;   // created from the built-in (unpinned) blob
     // batches up to these sizes take the cooperative (waves-per-signature) kernel: measured crossovers without /
     // with the subgroup check (tools/mode_crossover.py); SSA_COOP_MAX_N overrides both
-    size_t coop_max_n = 9216, coop_max_n_torsion = 12800;
+    size_t coop_max_n = 7680, coop_max_n_torsion = 10496;   // lane kernels: 3.5 / 5.4 ms flat up to 2^15 (round 2, window asm)
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;
 };
