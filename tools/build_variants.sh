@@ -9,8 +9,15 @@ for spec in "$@"; do
     name=${spec%%:*}
     flags=${spec#*:}
     echo "building $name ($flags)"
-    hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared $flags -o build/variants/$name.so \
-        schnorr-sig_amd/csrc/ssa_api.hip schnorr-sig_amd/csrc/ssa_msm.hip &
+    (
+        for u in ssa_api ssa_msm; do
+            hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -c -cuid=$u $flags -o build/variants/$name.$u.o \
+                schnorr-sig_amd/csrc/$u.hip &
+        done
+        wait
+        hipcc --offload-arch=gfx950 -fPIC -shared -o build/variants/$name.so build/variants/$name.ssa_api.o \
+            build/variants/$name.ssa_msm.o && rm -f build/variants/$name.ssa_api.o build/variants/$name.ssa_msm.o
+    ) &
 done
 wait
 ls -la build/variants
