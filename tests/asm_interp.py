@@ -136,8 +136,9 @@ class Lane:
             elif op == "s_branch":
                 pc = labels[a[0]]
             elif op == "s_and_b64":
-                kd, ka, kb = self._key(a[0]), self._key(a[1]), self._key(a[2])
-                self.s[kd] = self.s.get(ka, 0) & self.s.get(kb, 0)
+                bit = lambda o: getattr(self, "exec_bit", 1) if o.strip() == "exec" else self.s.get(self._key(o), 0)
+                kd = self._key(a[0])
+                self.s[kd] = bit(a[1]) & bit(a[2])
                 self.written_at[kd] = -100
             elif op in ("v_cmp_le_u32", "v_cmp_eq_u32", "v_cmp_ne_u32"):
                 x, y = self.rv(a[1]), self.rv(a[2])

@@ -344,8 +344,13 @@ def test_doubling_asm_declares_its_registers_and_kernels_leave_room():
         for lo, hi in set(re.findall(r"\bs\[(\d+):(\d+)\]", body)):
             assert all("s%d" % r in clob for r in range(int(lo), int(hi) + 1)), (name, lo)
         assert {"scc", "vcc"} <= clob and ("s20" in clob or "s20" not in body), name
-        if "exec" in body:       # EXEC is narrowed and restored inside the statement
+        if "saveexec" in body or "s_mov_b64 exec" in body:       # EXEC is narrowed and restored inside the statement
             assert body.count("s_and_saveexec_b64") == 1 and "s_mov_b64 exec, s[22:23]" in body
+        # a branch on VCC reads a VCC the scalar unit wrote (s_and_b64 vcc, exec, vcc after the VALU compare)
+        lines_ = [ln.strip().strip('"').replace("\\n\\t", "") for ln in body.split("\n")]
+        for i, ln in enumerate(lines_):
+            if ln.startswith("s_cbranch_vcc"):
+                assert lines_[i - 1] == "s_and_b64 vcc, exec, vcc", (name, i)
     src = open(os.path.join(os.path.dirname(INC), "ssa_kernels.hpp")).read()
     for m in re.finditer(r"__global__ void\s*(__launch_bounds__\(([^)]*)\))?[^{;]*?\b(ssa_k_\w+)\(.*?\n}\n", src, re.S):
         if re.search(r"mul_ptab\(|jac_dbl_n\(|add_base_mul\(|jac_madd_fast\(", m.group(0)):

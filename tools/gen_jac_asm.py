@@ -56,6 +56,9 @@ class Alloc:
 
 
 THRESH = "0xffffff00"
+# between a VALU compare into VCC and the branch on it: the compiler's own idiom (the branch then reads a VCC written by
+# the scalar unit, whose read of the VALU result is interlocked; lanes outside EXEC cannot take the wave to a cold path)
+VCC_ACTIVE = "s_and_b64 vcc, exec, vcc"
 
 
 class Gen:
@@ -85,7 +88,6 @@ class Gen:
         site = self.nsite
         self.nsite += 1
         out = self.main
-        guard_words = []
         # constant multiples (two sets of temporaries, alternating)
         for n, (dst, j, c) in enumerate(mulc):
             q, t, uh = self.Q[n % 2], self.T[n % 2], self.UH[n % 2]
@@ -109,7 +111,8 @@ class Gen:
         for dst, sp in dbl_of:
             body += self._dbl(dst, sp)
         out += body
-        out += ["v_cmp_le_u32 vcc, %s, v%d" % (THRESH, self.G), "s_cbranch_vccnz L_%scold%d_%%=" % (self.tag, site), "L_%scont%d_%%=:" % (self.tag, site)]
+        out += ["v_cmp_le_u32 vcc, %s, v%d" % (THRESH, self.G), VCC_ACTIVE, "s_cbranch_vccnz L_%scold%d_%%=" % (self.tag, site),
+                "L_%scont%d_%%=:" % (self.tag, site)]
         # cold path
         cold = ["L_%scold%d_%%=:" % (self.tag, site)]
         for _, j in dbl:
@@ -213,7 +216,8 @@ class Gen:
             for j in js:
                 body += ["v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (dst[j] + 1, carr[j % 3], dst[j] + 1, msk[j % 3], carr[j % 3])]
         # the guard sees the operands BEFORE they are overwritten; the cold path canonicalises them and rejoins
-        out += ["v_cmp_le_u32 vcc, %s, v%d" % (THRESH, self.G), "s_cbranch_vccnz L_%scold%d_%%=" % (self.tag, site), "L_%scont%d_%%=:" % (self.tag, site)]
+        out += ["v_cmp_le_u32 vcc, %s, v%d" % (THRESH, self.G), VCC_ACTIVE, "s_cbranch_vccnz L_%scold%d_%%=" % (self.tag, site),
+                "L_%scont%d_%%=:" % (self.tag, site)]
         out += body
         cold = ["L_%scold%d_%%=:" % (self.tag, site)]
         for j in range(6):
@@ -334,7 +338,7 @@ def build_madd(tag=""):
     gen.main += gen.zero_word(w, ZR[0])
     gen.main += ["v_mov_b32 v%d, v%d" % (gen.MASK, w)]
     gen.main += gen.zero_word(w, x2[0])
-    gen.main += ["v_min_u32 v%d, v%d, v%d" % (gen.MASK, gen.MASK, w), "v_cmp_eq_u32 vcc, 0, v%d" % gen.MASK,
+    gen.main += ["v_min_u32 v%d, v%d, v%d" % (gen.MASK, gen.MASK, w), "v_cmp_eq_u32 vcc, 0, v%d" % gen.MASK, VCC_ACTIVE,
                  "s_cbranch_vccnz L_bail_%="]
     # 1. Z1Z1 = Z^2, T = y2 * Z
     d, s, t, _ = pres(gen, ZR, 1, 1, 4)
@@ -346,7 +350,7 @@ def build_madd(tag=""):
     gen.block(g6.mul_terms(), mul_regs(T, Z1Z1, s), R, extras=[(-1, 1, "x")], extra_regs={"x": YR})
     # exceptional inputs, part 2: H == 0 (P == +-Q)
     gen.main += gen.zero_word(w, H[0])
-    gen.main += ["v_cmp_eq_u32 vcc, 0, v%d" % w, "s_cbranch_vccnz L_bail_%="]
+    gen.main += ["v_cmp_eq_u32 vcc, 0, v%d" % w, VCC_ACTIVE, "s_cbranch_vccnz L_bail_%="]
     # 3. HH = H^2, Z3 = Z H, HHH = HH H
     d, s, t, _ = pres(gen, H, 1, 1, 4)
     gen.block(g6.sqr_terms(), sqr_regs(H, d, s, t), HH)
