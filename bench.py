@@ -418,19 +418,27 @@ def main():
                        "ssa_multi_verify_batch_msm when one process owns the whole batch)"}
 
     # ---- host-buffer entry point (what the Rust shim binds): PCIe-inclusive, never `value` ----
+    # (the legs after the timed region are reported beside the metric: a failure inside one of them is recorded in its
+    # field and must not take the headline line with it)
+    def guarded(fn, *a, **kw):
+        try:
+            return fn(*a, **kw)
+        except Exception as exc:          # noqa: BLE001 -- reported, not swallowed
+            return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     host_path = None
     if legs and rank == 0 and n > 0 and hasattr(eng, "host_path_probe"):
-        host_path = eng.host_path_probe(sigs, pks, msgs, n, reps=3)
+        host_path = guarded(eng.host_path_probe, sigs, pks, msgs, n, reps=3)
 
     # ---- keyed context: repeated public keys (validator sets), Signature::verify semantics ----
     keyed = None
     if legs and rank == 0 and n > 0 and hasattr(eng, "keyset_create"):
-        keyed = keyed_leg(torch, eng, dev, g, min(n, 1 << 20))
+        keyed = guarded(keyed_leg, torch, eng, dev, g, min(n, 1 << 20))
 
     # ---- config 4 beside the weak run: one 2^22 batch, rank 0 -> shards, verified once per step ----
     config4 = None
     if legs and world > 1 and not strong and not args.no_strong_leg:
-        config4 = strong_leg(rk, eng, args.strong_total)
+        config4 = guarded(strong_leg, rk, eng, args.strong_total)
 
     if rank == 0:
         value = n_all * args.steps / elapsed
