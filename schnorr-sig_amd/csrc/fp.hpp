@@ -218,37 +218,24 @@ SSA_DEV u64 acc_reduce(const fp_acc &s) {
     return fp_reduce_parts(mk64(w0, w1), w2, mk64(w3, w4));
 }
 
-// x^(p-2) by a fixed chain: p - 2 = 0xfffffffeffffffff = 2^64 - 2^32 - 1
+// x^(p-2) by a fixed chain: p - 2 = 2^64 - 2^32 - 1 = (2^31 - 1) 2^33 + (2^32 - 1): 64 squarings + 10 products
+// (round 1's chain built 2^32 - 1 and 2^31 - 1 separately: 86 + 12)
+SSA_DEV u64 fp_sqr_times(u64 x, int n) {
+#pragma unroll 1
+    for (int i = 0; i < n; i++) x = fp_sqr(x);
+    return x;
+}
 SSA_DEV u64 fp_inv(u64 x) {
-    // x^(2^k - 1) ladders
-    u64 x2 = fp_mul(fp_sqr(x), x);                 // 2^2-1
-    u64 x4 = x2;
-    for (int i = 0; i < 2; i++) x4 = fp_sqr(x4);
-    x4 = fp_mul(x4, x2);                           // 2^4-1
-    u64 x8 = x4;
-    for (int i = 0; i < 4; i++) x8 = fp_sqr(x8);
-    x8 = fp_mul(x8, x4);                           // 2^8-1
-    u64 x16 = x8;
-    for (int i = 0; i < 8; i++) x16 = fp_sqr(x16);
-    x16 = fp_mul(x16, x8);                         // 2^16-1
-    u64 x32 = x16;
-    for (int i = 0; i < 16; i++) x32 = fp_sqr(x32);
-    x32 = fp_mul(x32, x16);                        // 2^32-1
-    // exponent bits (msb first): 31 ones, a zero, 32 ones  => x^( (2^31-1)*2^33 + 2^32-1 )
-    // x^(2^31-1) = (x^(2^16-1))^(2^15) * x^(2^15-1); build 2^15-1 from 2^8-1, 2^4-1, 2^2-1, 1
-    u64 x12 = x8;
-    for (int i = 0; i < 4; i++) x12 = fp_sqr(x12);
-    x12 = fp_mul(x12, x4);                         // 2^12-1
-    u64 x14 = x12;
-    for (int i = 0; i < 2; i++) x14 = fp_sqr(x14);
-    x14 = fp_mul(x14, x2);                         // 2^14-1
-    u64 x15 = fp_mul(fp_sqr(x14), x);              // 2^15-1
-    u64 x31 = x16;
-    for (int i = 0; i < 15; i++) x31 = fp_sqr(x31);
-    x31 = fp_mul(x31, x15);                        // 2^31-1
-    u64 r = x31;
-    for (int i = 0; i < 33; i++) r = fp_sqr(r);    // one zero bit + 32 positions
-    return fp_mul(r, x32);
+    const u64 x2 = fp_mul(fp_sqr(x), x);                    // x^(2^2 - 1)
+    const u64 x4 = fp_mul(fp_sqr_times(x2, 2), x2);         // 2^4 - 1
+    const u64 x8 = fp_mul(fp_sqr_times(x4, 4), x4);         // 2^8 - 1
+    const u64 x16 = fp_mul(fp_sqr_times(x8, 8), x8);        // 2^16 - 1
+    const u64 x24 = fp_mul(fp_sqr_times(x16, 8), x8);       // 2^24 - 1
+    const u64 x28 = fp_mul(fp_sqr_times(x24, 4), x4);       // 2^28 - 1
+    const u64 x30 = fp_mul(fp_sqr_times(x28, 2), x2);       // 2^30 - 1
+    const u64 x31 = fp_mul(fp_sqr(x30), x);                 // 2^31 - 1
+    const u64 x32 = fp_mul(fp_sqr(x31), x);                 // 2^32 - 1
+    return fp_mul(fp_sqr_times(x31, 33), x32);
 }
 
 }  // namespace ssa

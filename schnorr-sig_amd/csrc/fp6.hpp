@@ -391,11 +391,12 @@ SSA_DEV bool fp_is_square(u64 n) {
 SSA_DEV bool f6_is_square(const fp6 &a) { return fp_is_square(f6_norm(a)); }
 
 // a^-1 = (prod_{k=1..5} frob_k(a)) / N(a), with N(a) = a * prod in Fp.  a != 0 required.
+// The product of the five conjugates by three multiplications: b = a^p, c = b b^p = a^(p + p^2),
+// d = c c^(p^2) = a^(p + .. + p^4), t = d a^(p^5).
 SSA_DEV fp6 f6_inv(const fp6 &a) {
-    fp6 t = f6_mul(f6_frob<1>(a), f6_frob<2>(a));
-    t = f6_mul(t, f6_frob<3>(a));
-    t = f6_mul(t, f6_frob<4>(a));
-    t = f6_mul(t, f6_frob<5>(a));
+    const fp6 b = f6_frob<1>(a);
+    const fp6 c = f6_mul(b, f6_frob<1>(b));
+    fp6 t = f6_mul(f6_mul(c, f6_frob<2>(c)), f6_frob<5>(a));
     // only c0 of a*t is non-zero
     fp_acc s;
     acc_init(s, a.c[0], t.c[0]);

@@ -247,6 +247,62 @@ SSA_FN void tab_madd(u64 *__restrict__ dst, const u64 *__restrict__ src, const u
     st_row(dst, jac_madd(ld_row(src), ld_aff(paff)));
 }
 
+// The table of a GENERIC key without the Jacobian detour: affine doublings / additions whose denominators are inverted
+// together -- 2P alone, then {3P = 2P + P, 4P = 2(2P)}, then {5P = 4P + P, 6P = 2(3P), 7P = 4P + 3P, 8P = 2(4P)}:
+// three Fp6 inversions + 26 products + 11 squarings (~27 k instructions) instead of four Jacobian doublings, three
+// mixed additions, one inversion and seven normalisations (~52 k).  A zero denominator (keys of order 2 or 5: some
+// multiple is the identity or two operands coincide) makes it return false before anything is relied upon, and the
+// caller builds the table the exact, slower way.
+SSA_DEV fp6 aff_dbl_num(const fp6 &x) {          // 3 x^2 + a, a = 1
+    const fp6 xx = f6_sqr(x);
+    fp6 n = f6_add(f6_dbl(xx), xx);
+    n.c[0] = fp_add(n.c[0], 1ull);
+    return n;
+}
+SSA_DEV aff aff_from_slope(const fp6 &l, const fp6 &x1, const fp6 &y1, const fp6 &x2) {   // x3 = l^2 - x1 - x2
+    aff r;
+    r.x = f6_sub(f6_sub(f6_sqr(l), x1), x2);
+    r.y = f6_sub(f6_mul(l, f6_sub(x1, r.x)), y1);
+    return r;
+}
+SSA_DEV void st_tab_entry(u64 *__restrict__ row, const aff &a) {
+    st_aff(row, a);
+    st_f6(row + PTAB_NY, f6_neg(a.y));
+}
+SSA_DEV bool build_ptab_affine(u64 *__restrict__ tab, const aff &p) {
+    constexpr int R = PTAB_ENTRY_U64;
+    // 2P
+    const fp6 d2 = f6_dbl(p.y);
+    if (f6_is_zero(d2)) return false;
+    const aff p2 = aff_from_slope(f6_mul(aff_dbl_num(p.x), f6_inv(d2)), p.x, p.y, p.x);
+    // 3P = 2P + P, 4P = 2(2P)
+    const fp6 a3 = f6_sub(p2.x, p.x), a4 = f6_dbl(p2.y);
+    const fp6 t34 = f6_mul(a3, a4);
+    if (f6_is_zero(t34)) return false;
+    const fp6 i34 = f6_inv(t34);
+    const aff p3 = aff_from_slope(f6_mul(f6_sub(p2.y, p.y), f6_mul(i34, a4)), p.x, p.y, p2.x);
+    const aff p4 = aff_from_slope(f6_mul(aff_dbl_num(p2.x), f6_mul(i34, a3)), p2.x, p2.y, p2.x);
+    // 5P = 4P + P, 6P = 2(3P), 7P = 4P + 3P, 8P = 2(4P)
+    const fp6 a5 = f6_sub(p4.x, p.x), a6 = f6_dbl(p3.y), a7 = f6_sub(p4.x, p3.x), a8 = f6_dbl(p4.y);
+    const fp6 t56 = f6_mul(a5, a6), t567 = f6_mul(t56, a7), t5678 = f6_mul(t567, a8);
+    if (f6_is_zero(t5678)) return false;
+    fp6 inv = f6_inv(t5678);
+    const fp6 i8 = f6_mul(inv, t567);
+    inv = f6_mul(inv, a8);
+    const fp6 i7 = f6_mul(inv, t56);
+    inv = f6_mul(inv, a7);
+    const fp6 i6 = f6_mul(inv, a5), i5 = f6_mul(inv, a6);
+    st_tab_entry(tab, p);
+    st_tab_entry(tab + 1 * R, p2);
+    st_tab_entry(tab + 2 * R, p3);
+    st_tab_entry(tab + 3 * R, p4);
+    st_tab_entry(tab + 4 * R, aff_from_slope(f6_mul(f6_sub(p4.y, p.y), i5), p.x, p.y, p4.x));
+    st_tab_entry(tab + 5 * R, aff_from_slope(f6_mul(aff_dbl_num(p3.x), i6), p3.x, p3.y, p3.x));
+    st_tab_entry(tab + 6 * R, aff_from_slope(f6_mul(f6_sub(p4.y, p3.y), i7), p3.x, p3.y, p4.x));
+    st_tab_entry(tab + 7 * R, aff_from_slope(f6_mul(aff_dbl_num(p4.x), i8), p4.x, p4.y, p4.x));
+    return true;
+}
+
 // Affine multiples 1P..8P of a lane's point into its table rows: 4 doublings + 3 mixed additions
 // in Jacobian form, then one shared inversion (Montgomery's trick) to make every entry affine.
 // Multiples that are the identity (P of order <= 8: E(Fp6) has cofactor 2*5*29*...) are stored as
@@ -264,6 +320,9 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
         }
         return;
     }
+#ifndef SSA_PTAB_JACOBIAN_ONLY
+    if (build_ptab_affine(tab, p)) return;        // every key outside the few of order 2 or 5
+#endif
     st_row(tab, jac_from_aff(p));                 // row 0 doubles as affine P: (x, y, Z = 1)
     tab_dbl(tab + 1 * R, tab);                    // 2P
     tab_madd(tab + 2 * R, tab + 1 * R, tab);      // 3P = 2P + P
