@@ -13,7 +13,7 @@
 //   3. msm_k_buckets   ONE BUCKET PER LANE: a lane adds up the points of its bucket with mixed
 //                      additions (every exceptional case handled: equal public keys land in one bucket)
 //   4. msm_k_chunks    running-sum trick on chunks of 8 buckets (short chains, 2^17 lanes);
-//                      msm_k_tree (x5) sums the chunk sums of a window; msm_k_finish is ONE cooperative
+//                      msm_k_tree (pairwise, x13) sums the chunk sums of a window; msm_k_finish is ONE cooperative
 //                      block: wave 0 combines the windows by Horner's rule (the only long sequential chain
 //                      of the method, ~240 doublings, wave-cooperative Fp6 arithmetic), wave 1 computes
 //                      [lin]G from the comb table meanwhile; then the x coordinates are compared
@@ -28,7 +28,7 @@
 namespace ssa {
 
 constexpr int MSM_CHUNK = 8;   // buckets per lane in the running-sum pass (short chains, many lanes)
-constexpr u32 MSM_TREE_GROUP = 8;
+constexpr u32 MSM_TREE_GROUP = 2;   // pairwise: the tree is latency-bound (lone waves), 13 levels of ONE addition beat 5 of eight
 
 struct MsmShape {
     u32 c;        // window bits
@@ -192,9 +192,10 @@ msm_k_chunks(const u64 *__restrict__ bsum, MsmShape sh, u64 *__restrict__ chunk_
     const u32 j = (u32)(t / sh.chunks), ch = (u32)(t % sh.chunks);
     const u32 len = sh.buckets < (u32)MSM_CHUNK ? sh.buckets : (u32)MSM_CHUNK;
     const u32 v0 = ch * len;
-    jac running = jac_identity(), total = jac_identity();
+    // the top bucket opens both sums (two additions to the identity saved per chunk)
+    jac running = ld_jac(bsum + 18 * ((size_t)j * sh.buckets + (v0 + len - 1))), total = running;
 #pragma unroll 1
-    for (int v = (int)(v0 + len) - 1; v >= (int)v0; v--) {
+    for (int v = (int)(v0 + len) - 2; v >= (int)v0; v--) {
         if (v == 0) break;
         const jac b = ld_jac(bsum + 18 * ((size_t)j * sh.buckets + (u32)v));
         running = jac_add(running, b);
@@ -222,9 +223,9 @@ msm_k_tree(const u64 *__restrict__ in, u32 windows, u32 count, u32 group, u64 *_
     if (t >= windows * groups) return;
     const u32 j = t / groups, g = t % groups;
     const u32 lo = g * group, hi = (lo + group < count) ? lo + group : count;
-    jac acc = jac_identity();
+    jac acc = ld_jac(in + 18 * ((size_t)j * count + lo));        // (lo < hi always: groups = ceil(count / group))
 #pragma unroll 1
-    for (u32 k = lo; k < hi; k++) acc = jac_add(acc, ld_jac(in + 18 * ((size_t)j * count + k)));
+    for (u32 k = lo + 1; k < hi; k++) acc = jac_add(acc, ld_jac(in + 18 * ((size_t)j * count + k)));
     st_jac(out + 18 * (size_t)t, acc);
 }
 
