@@ -22,6 +22,10 @@ Modes:
                    each rank verifying its contiguous shard
 With N > 1 the weak run also carries a short config-4 leg (`config4_strong`) so that one driver
 invocation records both.
+  --force-dist     (or SSA_BENCH_FORCE_DIST=1) the process-group path at ANY world size, N = 1 included: a one-rank
+                   `nccl` group is initialised and every collective of the N > 1 run (scatter, broadcast, all-reduce,
+                   all-gather of the MSM records, max-over-ranks, the config-4 leg) executes through RCCL on device
+                   tensors -- the rehearsal of the multi-GPU code on a one-GPU box (tests/test_gpu_round3.py)
 """
 import argparse
 import hashlib
@@ -50,6 +54,12 @@ W_VERIFY_KERNEL = W_TABLE + W_LADDER + W_BASE + W_FINAL
 W_VERIFY_KEYED = W_LADDER + W_BASE + F6_MUL + F6_SQR   # keyed context: table and key checks are cached
 W_VERIFY_KEYED_COMB = (32 + 16) * W_MADD + F6_MUL + F6_SQR   # per-key comb: no doublings at all
 W_TORSION = W_LADDER
+# what the kernel EXECUTES ("The ladder window as one statement"): the re-arranged doubling runs 234 products
+# (M = ZZ^2 + 3 X^2 as one 42-product accumulation), the mixed addition 330, the per-lane table is built in affine
+# coordinates with three shared inversions (3 I + 26 M + 11 S); the comb additions and the final compare are unchanged
+W_DBL_EXEC, W_MADD_EXEC = 234, 330
+W_TABLE_EXEC = 3 * W_INV + 26 * F6_MUL + 11 * F6_SQR
+W_VERIFY_EXECUTED = W_TABLE_EXEC + 252 * W_DBL_EXEC + 63 * W_MADD_EXEC + 16 * W_MADD_EXEC + W_FINAL
 W_HASH = 4 * 7 * (12 * 4 + 12 * 72 + 2 * 144)   # 4 permutations x 7 rounds (80-byte message)
 BYTES_PER_VERIFY = 81 + 96 + 80 + 1             # algorithmic HBM bytes
 # Peak of the multiplier, measured in round 2 (tools/isa_probe, DESIGN.md "instruction cost table"): v_mad_u64_u32
@@ -78,10 +88,18 @@ def parse_args(argv=None):
                     help="profiling runs: only the timed steps (no torsion / MSM / host-path / keyed legs)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N>1 weak run: skip the config-4 leg")
     ap.add_argument("--strong-total", type=int, default=1 << 22, help="batch size of the config-4 leg")
+    ap.add_argument("--force-dist", action="store_true",
+                    default=os.environ.get("SSA_BENCH_FORCE_DIST", "") not in ("", "0"),
+                    help="initialise the process group and run every collective even at world size 1")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="rank/launch/collective plumbing with NO GPU work (CPU test of the N>1 launch path; "
                          "prints value 0 and \"plumbing_only\": true -- never a measurement)")
     return ap.parse_args(argv)
+
+
+def pow2_label(n):
+    """2^k for powers of two, the plain number otherwise (the workload label follows the batch actually run)"""
+    return "2^%d" % (n.bit_length() - 1) if n > 0 and n & (n - 1) == 0 else str(n)
 
 
 def free_port():
@@ -165,19 +183,28 @@ class Ranks:
                 self.dev_index = self.local_rank
             else:       # rehearsal backend on a box with fewer GPUs than ranks: ranks share devices
                 self.dev_index = self.local_rank % max(ndev, 1)
-        if self.world > 1:
-            import torch.distributed as dist
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
-            else:
-                dist.init_process_group(self.backend)
-            assert dist.get_world_size() == args.gpus and dist.get_rank() == self.rank
-            self.dist = dist
+        # the device is selected BEFORE the process group exists: RCCL binds its communicator to the current device
         if self.dev_index is not None:
             torch.cuda.set_device(self.dev_index)
             self.dev = torch.device("cuda", self.dev_index)
         else:
             self.dev = torch.device("cpu")
+        self.forced = bool(args.force_dist) and self.world == 1
+        if self.world > 1 or self.forced:
+            import torch.distributed as dist
+            if self.forced:      # no launcher set the rendezvous up: a one-rank group on the loopback
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(free_port()))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.dev_index))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            assert dist.get_world_size() == args.gpus and dist.get_rank() == self.rank
+            self.dist = dist
 
     @property
     def on_device_collectives(self):
@@ -200,6 +227,16 @@ class Ranks:
         t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.on_device_collectives else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def msm_verdict(self, record, combine):
+        """MSM-form verdict over the ranks (schnorr_sig_amd.sharding.msm_verdict): all-gather of the 24-word shard
+        records on the device (RCCL), or through the host for the rehearsal backend"""
+        from schnorr_sig_amd.sharding import msm_verdict
+        if self.on_device_collectives:
+            return msm_verdict(record, self.world, self.dist, combine)[0]
+        self.torch.cuda.current_stream().synchronize()
+        _, recs = msm_verdict(record.cpu(), self.world, self.dist, lambda r: None)
+        return combine(recs.to(record.device))
 
     def sync_all(self):
         if self.dist is not None:
@@ -393,14 +430,28 @@ def main():
         total_fail_t = int(nfail.item())
 
     # ---- the reference's own MSM-form verify_batch (one verdict per batch), 3 steps ----
+    # one process: ssa_verify_batch_msm_device.  Several ranks: every rank reduces its shard to one 24-word record
+    # (ssa_verify_batch_msm_partial_device), the records are all-gathered (24 words per rank: the only traffic) and
+    # combined on every rank (ssa_msm_combine_device: one point addition per shard, [sum]G, x-only compare) --
+    # SURVEY.md 8(e), reference src/batch.rs:98-129.  A rank with an empty shard still takes part in the collective.
     msm = None
-    if legs and n > 0:
-        coeffs = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device=dev, generator=g)
-        verdict = torch.zeros(1, dtype=torch.int32, device=dev)
+    if legs and (n > 0 or rk.dist is not None):
+        coeffs = torch.randint(0, 256, (max(n, 1), 16), dtype=torch.uint8, device=dev, generator=g)
+        verdict = torch.full((1,), 255, dtype=torch.int32, device=dev)
+        record = torch.zeros(24, dtype=torch.int64, device=dev)
+
+        def combine(records):
+            eng.msm_combine_device(records.data_ptr(), records.shape[0], verdict.data_ptr())
+            return verdict
 
         def msm_step():
-            eng.verify_batch_msm_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, coeffs.data_ptr(),
-                                        16, verdict.data_ptr())
+            if rk.dist is None:
+                eng.verify_batch_msm_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, coeffs.data_ptr(),
+                                            16, verdict.data_ptr())
+            else:
+                eng.verify_batch_msm_partial_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80,
+                                                    coeffs.data_ptr(), 16, record.data_ptr())
+                rk.msm_verdict(record, combine)
         msm_step()
         rk.sync_all()
         eng.enable_timing(True)
@@ -411,11 +462,13 @@ def main():
         dt = rk.max_over_ranks(time.perf_counter() - t3)
         eng.enable_timing(False)
         stages = {k: eng.read_timing(k)[0] for k in ("ssa_k_hash", "msm_k_prepare", "msm_sort", "msm_k_buckets",
-                                                     "msm_reduce")}
+                                                     "msm_reduce", "msm_combine")}
         msm = {"verifications_per_sec": n_all * 3 / dt, "ms_per_batch": dt / 3 * 1e3,
                "verdict": int(verdict.item()), "expected_verdict": 2 if args.corrupt > 0 else 0, "stages_ms": stages,
-               "note": "one verdict per rank-local shard (per-device partial sums are combined by "
-                       "ssa_multi_verify_batch_msm when one process owns the whole batch)"}
+               "combined_over_ranks": rk.dist is not None,
+               "note": ("ONE verdict for the %d signatures of all %d rank(s): per-rank shard records all-gathered "
+                        "(24 words each) and combined on every rank" % (n_all, world)) if rk.dist is not None else
+                       "one verdict for this process's batch"}
 
     # ---- host-buffer entry point (what the Rust shim binds): PCIe-inclusive, never `value` ----
     # (the legs after the timed region are reported beside the metric: a failure inside one of them is recorded in its
@@ -437,7 +490,7 @@ def main():
 
     # ---- config 4 beside the weak run: one 2^22 batch, rank 0 -> shards, verified once per step ----
     config4 = None
-    if legs and world > 1 and not strong and not args.no_strong_leg:
+    if legs and rk.dist is not None and not strong and not args.no_strong_leg:
         config4 = guarded(strong_leg, rk, eng, args.strong_total)
 
     if rank == 0:
@@ -453,8 +506,10 @@ def main():
         except Exception:
             pass
         unpinned = eng.uses_default_params() if hasattr(eng, "uses_default_params") else True
-        workload = ("config4: ONE batch of %d random-keypair signatures sharded over %d GPU(s)" % (n_all, world)
-                    if strong else "config3: 2^20 random-keypair signatures per GPU") + \
+        workload = ("config4: ONE batch of %s random-keypair signatures sharded over %d GPU(s)" % (pow2_label(n_all), world)
+                    if strong else "%s: %s random-keypair signatures per GPU%s"
+                    % ("config5" if args.corrupt > 0 else "config3", pow2_label(n),
+                       ", %g %% corrupted" % (100 * args.corrupt) if args.corrupt > 0 else "")) + \
             ", 80-byte distinct messages, full verify (Rescue hash + [h]P+[e]G + x-compare), verify_batch semantics"
         out = {
             "metric": metric,
@@ -471,7 +526,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "signatures_per_gpu": n, "signatures_total": n_all, "message_bytes": 80,
                        "parallelism": "shard%d" % world, "corrupt_fraction": args.corrupt,
-                       "backend": rk.backend if world > 1 else None},
+                       "backend": rk.backend if rk.dist is not None else None,
+                       "process_group": ("forced one-rank group (RCCL rehearsal)" if rk.forced else "torchrun ranks")
+                       if rk.dist is not None else None},
             "ranks": [list(d) for d in devices],
             "constants": "builder-default (unpinned)" if unpinned else "caller-supplied blob",
             "parity_unpinned": bool(unpinned),
@@ -505,7 +562,13 @@ def main():
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": pmc_src,
                 "algorithmic_bytes_per_launch": BYTES_PER_VERIFY * n,
-                "pmc": {k: pmc["ssa_k_verify"].get(k) for k in ("SQ_INSTS_VALU", "valu_mad_share", "valu_issue_utilisation",
+                "work_executed": W_VERIFY_EXECUTED,
+                "work_executed_note": "64x64 products the kernel really runs per verification (window statement: 234 per "
+                                      "doubling, 330 per mixed addition; affine table build) -- work_per_unit is the "
+                                      "textbook count kept fixed across rounds, DESIGN.md 'Work formula'",
+                "achieved_executed": (W_VERIFY_EXECUTED * n / (k_verify_ms * 1e-3) if k_verify_ms > 0 else 0.0) / 1e9,
+                "pmc": {k: pmc["ssa_k_verify"].get(k) for k in ("SQ_INSTS_VALU", "valu_cycles_per_instruction",
+                                                                  "valu_active_frac", "valu_instructions_per_product",
                                                                   "duration_ms")} if pmc else None,
             },
             "roofline_hash": {
@@ -660,6 +723,16 @@ def cpu_baseline(np, sigs, pks, msgs, gpu_status_batch_semantics, m):
     out["single_thread"] = {
         "signature_verify_per_sec": m1 / t_one, "verify_batch_msm_form_signatures_per_sec": m1 / t_msm,
         "verify_batch_msm_form_verdict": verdict_cpu, "sample": "first %d signatures, 1 thread" % m1}
+    # the MSM-form verify_batch on all hardware threads too (the restatement's MSM is the naive
+    # sum of n double-scalar products, parallel over signatures, partial sums added under a lock)
+    co_all = np.random.default_rng(12).integers(0, 256, size=(m, 32), dtype=np.uint8)
+    co_all[:, 16:] = 0
+    tc = time.perf_counter()
+    verdict_all = orc.verify_batch_msm(hs, hp, hm, co_all, threads=threads)
+    t_msm_all = time.perf_counter() - tc
+    out["all_threads_msm_form"] = {
+        "verify_batch_msm_form_signatures_per_sec": m / t_msm_all, "verify_batch_msm_form_verdict": verdict_all,
+        "cores": threads, "sample": "first %d signatures, %d threads" % (m, threads)}
     return out
 
 

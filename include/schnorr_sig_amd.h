@@ -211,7 +211,8 @@ int ssa_ctx_sync(ssa_ctx *ctx);
  * ssa_verify_many_indexed then verifies signature i against key key_idx[i] starting at the ladder.  Same
  * statuses as ssa_verify_many (a key that failed its subgroup check gives SSA_INVALID_PUBLIC_KEY under
  * SSA_FLAG_CHECK_TORSION; an index >= m gives SSA_MALFORMED).  A key set belongs to the context it was created
- * on; destroy it before the context. */
+ * on.  Destroy it before the context; one that outlives its context is orphaned by ssa_ctx_destroy (its tables are
+ * freed there, every call on it but ssa_keyset_destroy returns SSA_ERR_ARG), never a dangling pointer. */
 typedef struct ssa_keyset ssa_keyset;
 /* table kind: SSA_KEYSET_LADDER keeps eight multiples per key (2 KB; verification runs the 252-doubling ladder),
  * SSA_KEYSET_COMB a comb of [d * 2^(8w)]P, w < 32, d < 256 per key (768 KB; [h]P becomes 32 mixed additions, no
@@ -252,6 +253,39 @@ int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, const uint8_t 
                                const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
                                size_t n, const uint8_t *coeffs);
 
+/* ---- MSM-form verify_batch across PROCESSES (one process per GPU, torch.distributed / RCCL) ----------------
+ * The same split as ssa_multi_verify_batch_msm, with the exchange left to the caller ("in the MSM
+ * form, one point addition per shard + one compare", src/batch.rs:98-129): every rank reduces ITS shard to one
+ * record of SSA_MSM_PARTIAL_WORDS u64 --
+ *     words 0..17  the shard's left-hand point  sum s_i R_i - sum (s_i h_i) P_i  (Jacobian X, Y, Z, canonical limbs)
+ *     words 18..21 sum s_i e_i mod q            word 22  non-zero: the shard holds an input the reference panics on
+ *     word 23      reserved (0)
+ * -- the ranks all-gather the records (24 words per rank: the only traffic), and ssa_msm_combine adds the k points
+ * up (one Jacobian addition per shard), computes [sum]G from the comb table and compares x coordinates exactly as
+ * the single-context call does.  An empty shard (n == 0) gives the all-zero record (the identity and 0).
+ * Coefficients as in ssa_verify_batch_msm_device (NULL: drawn per call on the device; every rank draws its own). */
+#define SSA_MSM_PARTIAL_WORDS 24
+int ssa_verify_batch_msm_partial_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
+                                        const uint8_t *d_pk_inf, const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                        size_t msg_stride, size_t msg_len, size_t n, const uint8_t *d_coeffs,
+                                        uint32_t coeff_bytes, uint64_t *d_partial_out);
+/* host-buffer form (coeffs: n x 32 bytes or NULL); out24 is host memory */
+int ssa_verify_batch_msm_partial(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                 const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
+                                 size_t n, const uint8_t *coeffs, uint64_t out24[SSA_MSM_PARTIAL_WORDS]);
+/* k records (k x 24 words, device memory) -> *d_verdict_out = SSA_OK / SSA_INVALID_SIGNATURE / SSA_MALFORMED,
+ * enqueued on the context's stream; 1 <= k <= 4096 */
+int ssa_msm_combine_device(ssa_ctx *ctx, const uint64_t *d_parts24, size_t k, uint32_t *d_verdict_out);
+/* the same from host memory; returns the status */
+int ssa_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k);
+
+/* ---- ABI version -------------------------------------------------------------------------------------------
+ * Bumped whenever an exported signature changes (round 2 inserted pk_inf into the batch entry points under the same
+ * symbol names: a shim built against the older header would still link and pass msgs as pk_inf).  A binding checks
+ * ssa_abi_version() == SSA_ABI_VERSION at load; the Python and C++ mirrors do. */
+#define SSA_ABI_VERSION 3
+int ssa_abi_version(void);
+
 /* ---- arithmetic probes (unit parity with the oracle; not part of the reference API) --- */
 /* op: 0 = Fp6 mul, 1 = Fp6 sqr, 2 = Fp6 inv, 3 = point add (affine 12+12 -> 12 felts + inf),
  *     4 = scalar mul [k]P (k in a[0..4], P in b), 5 = Fp mul (a[0]*b[0]), 6 = Fp inv,
@@ -263,7 +297,9 @@ int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, const uint8_t 
  *         canonicalised on the way in or out): a = X, Y, Z (18 words), a[18] = act, a[19] = n; b = x2, y2 (12 words)
  *         -> X, Y, Z (18 words) + out[18] = flag.  15 one ladder window (n doublings, then the mixed addition where
  *         act != 0; flag 0 = the addition met a possible exceptional input and was left to the caller),
- *         16 mixed addition with its exact fallback, 17 n doublings */
+ *         16 mixed addition with its exact fallback, 17 n doublings
+ *     18 = the Rescue S-boxes on raw loose values: a = (x, y) -> x^7, y^7, x^(1/7), y^(1/7) (canonical) and the flags of
+ *         the two generated blocks (non-zero: the block reported its rare reduction borrow and the lane was recomputed) */
 int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                     size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride);
 /* n_blocks 64-byte blocks of the ChaCha20 keystream the MSM coefficients come from (RFC 8439 known answers) */

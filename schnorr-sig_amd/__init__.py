@@ -65,11 +65,36 @@ class MalformedInput(ValueError):
     """Inputs on which the reference panics (src/signature.rs:186, src/batch.rs:37-44,67)."""
 
 
+def _share_hip_runtime_with_torch():
+    """ONE HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7) and
+    ask for it as `libamdhip64.so`; this library asks for `libamdhip64.so.7`.  With torch imported first the loader
+    gives us torch's copy (SONAME match); the other way round torch's name does not match /opt/rocm's copy, a second
+    runtime is loaded and finds no device ("No HIP GPUs are available").  A process that will use both (device tensors
+    handed to the *_device entry points) must share one: when torch is installed and not imported yet, its copy is
+    loaded first.  SSA_NO_TORCH_HIP_PRELOAD=1 turns this off (a process that never imports torch does not need it)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("SSA_NO_TORCH_HIP_PRELOAD"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass            # not loadable here (no ROCm userland around it): the system runtime serves
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "schnorr_sig_amd: HIP library %s is missing; run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     vp, sz, u32, u64p, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64), C.c_int
     sigs = {
@@ -110,14 +135,27 @@ def _load():
         "ssa_debug_arith": (i32, [vp, i32, vp, vp, sz, sz, sz, vp, sz]),
         "ssa_bench_fpmul": (i32, [vp, i32, C.POINTER(C.c_double)]),
         "ssa_debug_chacha20": (i32, [vp, vp, vp, u32, sz, vp]),
+        "ssa_verify_batch_msm_partial_device": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp, u32, vp]),
+        "ssa_verify_batch_msm_partial": (i32, [vp, vp, vp, vp, vp, vp, sz, sz, sz, vp, vp]),
+        "ssa_msm_combine_device": (i32, [vp, vp, sz, vp]),
+        "ssa_msm_combine": (i32, [vp, vp, sz]),
+        "ssa_abi_version": (i32, []),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here == ABI symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # a library built from another revision of include/schnorr_sig_amd.h would still resolve every symbol and then
+    # read its arguments shifted (round 2 inserted pk_inf into the batch entry points): refuse it at load
+    got = lib.ssa_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError("schnorr_sig_amd: %s has ABI version %d, this binding was written for %d -- rebuild "
+                          "(python -c 'import __graft_entry__ as g; g.build(force=True)')" % (LIB_PATH, got, ABI_VERSION))
     return lib, list(sigs)
 
 
+ABI_VERSION = 3        # SSA_ABI_VERSION of include/schnorr_sig_amd.h
+MSM_PARTIAL_WORDS = 24
 _lib, ABI_SYMBOLS = _load()
 
 
@@ -235,6 +273,39 @@ class Engine:
                                                 msg_stride if msg_stride is not None else msg_len, msg_len, n,
                                                 d_coeffs, coeff_bytes, d_verdict), "ssa_verify_batch_msm_device")
 
+    # ---- MSM-form verdict across processes: per-shard records + combination (include/schnorr_sig_amd.h) ----
+    def verify_batch_msm_partial_device(self, d_sigs, d_pks, d_msgs, n, msg_len, d_coeffs, coeff_bytes, d_partial24,
+                                        msg_stride=None, d_offsets=0, d_pk_inf=0):
+        """this rank's shard -> one 24-word record at device address d_partial24 (enqueued on the stream)"""
+        _check(_lib.ssa_verify_batch_msm_partial_device(
+            self._ctx, d_sigs, d_pks, d_pk_inf or None, d_msgs, d_offsets or None,
+            msg_stride if msg_stride is not None else msg_len, msg_len, n, d_coeffs or None, coeff_bytes, d_partial24),
+            "ssa_verify_batch_msm_partial_device")
+
+    def verify_batch_msm_partial(self, sigs, pks, msgs, offsets=None, coeffs=None, pk_inf=None):
+        """host buffers -> the shard's record as uint64[24]"""
+        sigs, pks = _np_u8(sigs, 81), _np_u8(pks, 96)
+        n = sigs.shape[0]
+        if n:
+            m, off, stride, mlen = self._msg_args(msgs, offsets, n)
+        else:
+            m, off, stride, mlen = None, None, 0, 0
+        c = _np_u8(coeffs, 32) if coeffs is not None else None
+        inf = _np_u8(pk_inf) if pk_inf is not None else None
+        out = np.zeros(MSM_PARTIAL_WORDS, dtype=np.uint64)
+        _check(_lib.ssa_verify_batch_msm_partial(self._ctx, _ptr(sigs) if n else None, _ptr(pks) if n else None,
+                                                 _ptr(inf), _ptr(m), _ptr(off), stride, mlen, n, _ptr(c), _ptr(out)),
+               "ssa_verify_batch_msm_partial")
+        return out
+
+    def msm_combine_device(self, d_parts24, k, d_verdict):
+        _check(_lib.ssa_msm_combine_device(self._ctx, d_parts24, k, d_verdict), "ssa_msm_combine_device")
+
+    def msm_combine(self, parts):
+        """uint64[k, 24] records (host) -> status of the whole batch"""
+        parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, MSM_PARTIAL_WORDS)
+        return _check(_lib.ssa_msm_combine(self._ctx, _ptr(parts), parts.shape[0]), "ssa_msm_combine")
+
     def debug_chacha20(self, key32, nonce12, counter0, n_blocks):
         """keystream blocks of the generator the MSM coefficients come from (RFC 8439 block function)"""
         key, nonce = _np_u8(bytearray(key32)), _np_u8(bytearray(nonce12))
@@ -306,27 +377,27 @@ class Engine:
 
     # ---- keyed context (many signatures by few signers) ---------------------------------
     def keyset_create(self, pks, pk_inf=None, kind="auto"):
-        """-> opaque key set handle: subgroup check and tables done once per key.  kind: "auto", "comb" (768 KB
+        """-> KeySet: subgroup check and tables done once per key.  kind: "auto", "comb" (768 KB
         per key, no doublings at verification time) or "ladder" (2 KB per key)"""
         pks = _np_u8(pks, 96)
         inf = _np_u8(pk_inf) if pk_inf is not None else None
         ks = C.c_void_p()
         _check(_lib.ssa_keyset_create(self._ctx, _ptr(pks), _ptr(inf), pks.shape[0], KEYSET_KINDS[kind], C.byref(ks)),
                "ssa_keyset_create")
-        return ks
+        return KeySet(self, ks, pks.shape[0])
 
     def keyset_create_device(self, d_pks, m, d_pk_inf=0, kind="auto"):
         ks = C.c_void_p()
         _check(_lib.ssa_keyset_create_device(self._ctx, d_pks, d_pk_inf or None, m, KEYSET_KINDS[kind], C.byref(ks)),
                "ssa_keyset_create_device")
-        return ks
+        return KeySet(self, ks, m)
 
     def keyset_destroy(self, ks):
-        _lib.ssa_keyset_destroy(ks)
+        ks.close()
 
-    def keyset_status(self, ks, m):
-        st = np.full(m, 255, dtype=np.uint8)
-        _check(_lib.ssa_keyset_status(ks, _ptr(st)), "ssa_keyset_status")
+    def keyset_status(self, ks, m=None):
+        st = np.full(ks.m if m is None else m, 255, dtype=np.uint8)
+        _check(_lib.ssa_keyset_status(ks.handle, _ptr(st)), "ssa_keyset_status")
         return st
 
     def verify_many_indexed(self, ks, key_idx, sigs, msgs, offsets=None, check_torsion=True, sig_flag_byte=False):
@@ -339,13 +410,13 @@ class Engine:
         status = np.full(n, 255, dtype=np.uint8)
         nfail = C.c_uint64(0)
         flags = (FLAG_CHECK_TORSION if check_torsion else 0) | (FLAG_SIG_FLAG_BYTE if sig_flag_byte else 0)
-        _check(_lib.ssa_verify_many_indexed(self._ctx, ks, _ptr(idx), _ptr(sigs), _ptr(m), _ptr(off), stride, mlen, n,
+        _check(_lib.ssa_verify_many_indexed(self._ctx, ks.handle, _ptr(idx), _ptr(sigs), _ptr(m), _ptr(off), stride, mlen, n,
                                             flags, _ptr(status), C.byref(nfail)), "ssa_verify_many_indexed")
         return status, int(nfail.value)
 
     def verify_many_indexed_device(self, ks, d_key_idx, d_sigs, d_msgs, n, msg_len, d_status, d_nfail, msg_stride=None,
                                    d_offsets=0, check_torsion=True):
-        _check(_lib.ssa_verify_many_indexed_device(self._ctx, ks, d_key_idx, d_sigs, d_msgs, d_offsets or None,
+        _check(_lib.ssa_verify_many_indexed_device(self._ctx, ks.handle, d_key_idx, d_sigs, d_msgs, d_offsets or None,
                                                    msg_stride if msg_stride is not None else msg_len, msg_len, n,
                                                    FLAG_CHECK_TORSION if check_torsion else 0, d_status, d_nfail),
                "ssa_verify_many_indexed_device")
@@ -424,6 +495,27 @@ class Engine:
         v = C.c_double(0)
         _check(_lib.ssa_bench_fpmul(self._ctx, variant, C.byref(v)), "ssa_bench_fpmul")
         return v.value
+
+
+class KeySet:
+    """ssa_keyset handle tied to its Engine: the engine cannot be collected before the key set, and the handle is
+    destroyed exactly once (close(), or when the object goes away)."""
+
+    def __init__(self, engine, handle, m):
+        self.engine = engine      # keeps the context alive
+        self.handle = handle
+        self.m = int(m)
+
+    def close(self):
+        if self.handle:
+            _lib.ssa_keyset_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MultiEngine:

@@ -79,6 +79,7 @@ SSA_DEV jac jac_dbl(const jac &p) {
 #include "jac_asm.inc"
 #endif
 SSA_DEV jac jac_dbl_n(jac p, u32 n) {
+    if (n == 0) return p;     // the generated loop counts down to zero: n == 0 would wrap to 2^32 iterations
 #ifdef SSA_JAC_ASM
     jac_dbl_n_asm(p.X.c, p.Y.c, p.Z.c, n);
     return p;

@@ -51,12 +51,25 @@ SSA_DEV u64 inv_sbox(u64 x) {
 }
 
 // Two state elements at a time, the whole chain of both in ONE asm block (fp_chain_asm.inc,
-// tools/gen_fp_chain_asm.py): 17 instructions per squaring and 20 per product instead of hipcc's 22-26 + s_nop
+// tools/gen_fp_chain_asm.py): 11 instructions per squaring and 15 per product instead of hipcc's 22-26 + s_nop
 // padding, the two values interleaved by a list scheduler so that the SGPR carries get their wait states.
+// The blocks do not repair the one rare event of their reduction (a borrow with probability ~2^-32 per squaring, see
+// the generator): they REPORT the lanes that met it and hand those lanes their inputs back, and the lanes are
+// recomputed with the compiled, exact chain.  ~1 lane in 3 * 10^5 hashes takes that branch.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SSA_NO_FP_CHAIN_ASM)
 #include "fp_chain_asm.inc"
-SSA_DEV void inv_sbox2(u64 &x, u64 &y) { inv_sbox2_asm(x, y); }
-SSA_DEV void sbox2(u64 &x, u64 &y) { sbox2_asm(x, y); }
+SSA_DEV void inv_sbox2(u64 &x, u64 &y) {
+    if (inv_sbox2_asm(x, y)) {      // flagged lanes get their inputs back (no copy is kept alive across the block)
+        x = inv_sbox(x);
+        y = inv_sbox(y);
+    }
+}
+SSA_DEV void sbox2(u64 &x, u64 &y) {
+    if (sbox2_asm(x, y)) {
+        x = sbox(x);
+        y = sbox(y);
+    }
+}
 #else
 SSA_DEV void inv_sbox2(u64 &x, u64 &y) {
     x = inv_sbox(x);

@@ -26,6 +26,22 @@ extern "C" const char *ssa_strerror(int rc) {
 
 extern "C" const void *ssa_default_params(void) { return k_default_params; }
 
+extern "C" int ssa_abi_version(void) { return SSA_ABI_VERSION; }
+
+// keyed context (defined here because ssa_ctx_destroy orphans the key sets that outlive their context)
+struct ssa_keyset {
+    ssa_ctx *ctx = nullptr;   // nullptr: the context is gone, the device memory went with it
+    size_t m = 0;
+    bool comb = false;      // per-key comb tables (768 KB per key) instead of the ladder's eight multiples
+    DevBuf tab, status, pks, ktab;
+    void release_all() {
+        tab.release();
+        status.release();
+        pks.release();
+        ktab.release();
+    }
+};
+
 static int validate_params(const DevParams &p) {
     if (std::memcmp(p.magic, "SSAPARM1", 8) != 0) return SSA_ERR_PARAMS;
     if (p.n_rounds == 0 || p.n_rounds > 8) return SSA_ERR_PARAMS;
@@ -89,6 +105,10 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
             ssa_ctx_destroy(ctx);
             return SSA_ERR_HIP;
         }
+    if (hipEventCreateWithFlags(&ctx->pipe_start, hipEventDisableTiming) != hipSuccess) {
+        ssa_ctx_destroy(ctx);
+        return SSA_ERR_HIP;
+    }
     for (int i = 0; i < 8; i++)
         if (hipEventCreateWithFlags(&ctx->copy_done[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->hash_done[i], hipEventDisableTiming) != hipSuccess) {
@@ -135,6 +155,13 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    // a key set that outlives its context (garbage-collection order of a binding) must not touch the dead stream:
+    // its tables are freed here, the handle stays valid for ssa_keyset_destroy and is refused everywhere else
+    for (ssa_keyset *ks : ctx->keysets) {
+        ks->release_all();
+        ks->ctx = nullptr;
+    }
+    ctx->keysets.clear();
     for (auto &kv : ctx->timed)
         for (auto &t : kv.second) {
             (void)hipEventDestroy(t.start);
@@ -145,7 +172,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
                       &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
                       &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
-                      &ctx->msm_ids, &ctx->msm_ids2})
+                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
@@ -153,6 +180,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->hash_done)
         if (ev) (void)hipEventDestroy(ev);
+    if (ctx->pipe_start) (void)hipEventDestroy(ctx->pipe_start);
     for (auto &st : ctx->hash_stream)
         if (st) (void)hipStreamDestroy(st);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -332,10 +360,9 @@ extern "C" int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compres
 static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                                  const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
                                  size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out, bool *used) {
-    PipelinedInputs pin;
-    PinnedRange r_status;
+    PipelinedInputs pin;      // its destructor drains the side streams on every error return below
     *used = false;
-    if (!r_status.pin(status_out, n)) return 0;
+    if (!pin.r_status.pin(status_out, n)) return 0;
     if (int rc = pipelined_upload_hash(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, pin, used)) return rc;
     if (!*used) return 0;
     if (ctx->st_status.reserve(n + 16) ||
@@ -353,6 +380,7 @@ static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_
     unsigned long long nf = 0;
     HIP_TRY(hipMemcpyAsync(&nf, d_fail, sizeof nf, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    pin.done();
     if (n_fail_out) *n_fail_out = nf;
     return 0;
 }
@@ -557,12 +585,6 @@ extern "C" int ssa_verify_keyed_many(ssa_ctx *ctx, const uint8_t *keyed, const u
 }
 
 // ------------------------------------------------------------------ keyed context
-struct ssa_keyset {
-    ssa_ctx *ctx = nullptr;
-    size_t m = 0;
-    bool comb = false;      // per-key comb tables (768 KB per key) instead of the ladder's eight multiples
-    DevBuf tab, status, pks, ktab;
-};
 
 extern "C" int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t m,
                                         uint32_t flags, ssa_keyset **out) {
@@ -608,6 +630,7 @@ extern "C" int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, cons
             return rc ? rc : SSA_ERR_HIP;
         }
     }
+    ctx->keysets.push_back(ks);
     *out = ks;
     return 0;
 }
@@ -628,16 +651,19 @@ extern "C" void ssa_keyset_destroy(ssa_keyset *ks) {
     if (ks->ctx) {
         (void)hipSetDevice(ks->ctx->device);
         (void)hipStreamSynchronize(ks->ctx->stream);
+        auto &v = ks->ctx->keysets;
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i] == ks) {
+                v.erase(v.begin() + (long)i);
+                break;
+            }
+        ks->release_all();
     }
-    ks->tab.release();
-    ks->status.release();
-    ks->pks.release();
-    ks->ktab.release();
     delete ks;
 }
 
 extern "C" int ssa_keyset_status(ssa_keyset *ks, uint8_t *status_out) {
-    if (!ks || !status_out) return SSA_ERR_ARG;
+    if (!ks || !ks->ctx || !status_out) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ks->ctx->device));
     HIP_TRY(hipMemcpyAsync(status_out, ks->status.p, ks->m, hipMemcpyDeviceToHost, ks->ctx->stream));
     HIP_TRY(hipStreamSynchronize(ks->ctx->stream));
@@ -807,7 +833,7 @@ extern "C" int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, con
             } else {
                 mbase = msgs ? msgs + lo * msg_stride : nullptr;
             }
-            rcs[r] = ssa_internal_msm_partial(m->ctxs[r], sigs + 81 * lo, pks + 96 * lo, pk_inf ? pk_inf + lo : nullptr,
+            rcs[r] = ssa_verify_batch_msm_partial(m->ctxs[r], sigs + 81 * lo, pks + 96 * lo, pk_inf ? pk_inf + lo : nullptr,
                                               mbase, offp, msg_stride, msg_len, cnt, coeffs ? coeffs + 32 * lo : nullptr,
                                               &parts[24 * r]);
         });
@@ -815,14 +841,24 @@ extern "C" int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, con
     for (auto &t : threads) t.join();
     for (size_t r = 0; r < world; r++)
         if (rcs[r] != 0) return rcs[r];
-    return ssa_internal_msm_combine(m->ctxs[0], parts.data(), world);
+    return ssa_msm_combine(m->ctxs[0], parts.data(), world);
 }
 
 // ------------------------------------------------------------------ probes
 extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                                size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {
-    if (!ctx || !a || !out || n == 0 || op < 0 || op > 17) return SSA_ERR_ARG;
-    if ((op == 0 || op == 3 || op == 4 || op == 5 || op >= 7) && !b) return SSA_ERR_ARG;
+    if (!ctx || !a || !out || n == 0 || op < 0 || op > 18) return SSA_ERR_ARG;
+    if ((op == 0 || op == 3 || op == 4 || op == 5 || (op >= 7 && op != 18)) && !b) return SSA_ERR_ARG;
+    if (op == 18 && (a_stride < 2 || out_stride < 6)) return SSA_ERR_ARG;
+    if (op >= 15 && op <= 17) {
+        // the generated loops take their count from a[19] through v_readfirstlane (wave-uniform) and count DOWN to
+        // zero: n == 0 would wrap to 2^32 iterations, rows that disagree would silently run lane 0's count
+        if (a_stride < 20 || b_stride < 12 || out_stride < 19) return SSA_ERR_ARG;
+        if (op != 16)
+            for (size_t i = 0; i < n; i++)
+                if (a[i * a_stride + 19] == 0 || a[i * a_stride + 19] > 64 || a[i * a_stride + 19] != a[19])
+                    return SSA_ERR_ARG;
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     const void *da, *db = nullptr;
     if (int rc = stage_up(ctx, ctx->st_aux, a, n * a_stride * 8, &da)) return rc;
@@ -833,7 +869,7 @@ extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const ui
     if (op == 7) {
         hipLaunchKernelGGL(ssa_k_debug_coop, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const u64 *)da,
                            (const u64 *)db, n, a_stride, b_stride, (u64 *)ctx->st_status.p, out_stride);
-    } else if (op == 4 || op >= 15) {
+    } else if (op == 4 || (op >= 15 && op <= 17)) {
         if (ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
         hipLaunchKernelGGL(ssa_k_debug_mul, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, op, (const u64 *)da,
                            (const u64 *)db, n, a_stride, b_stride, (u64 *)ctx->ws_tab.p,

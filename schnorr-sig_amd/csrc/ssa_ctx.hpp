@@ -63,6 +63,7 @@ struct ssa_ctx {
     hipEvent_t copy_done[8] = {};             // one per upload chunk
     hipStream_t hash_stream[2] = {};          // the chunks' hash launches alternate between two streams, so that the
     hipEvent_t hash_done[8] = {};             //   tail of one launch (a lane hashes for ~4 ms) overlaps the next
+    hipEvent_t pipe_start = nullptr;          // everything queued on `stream` before a pipelined upload began
     size_t pipeline_min_n = 1 << 17;          // host-buffer batches from this size on are uploaded in chunks
     unsigned pipeline_chunks = 8;             // SSA_PIPELINE_CHUNKS overrides (1 = off)
     DevParams *d_params = nullptr;
@@ -72,7 +73,8 @@ struct ssa_ctx {
     DevBuf st_sigs, st_pks, st_inf, st_msgs, st_off, st_status, st_aux, st_aux2;
     // MSM-form batch verification (ssa_msm.hip)
     DevBuf msm_points, msm_scalars, msm_keys, msm_vals, msm_keys2, msm_vals2, msm_sort_tmp, msm_bounds,
-        msm_buckets, msm_chunks, msm_windows, msm_partials, msm_flags, st_coeffs, msm_cnt, msm_cnt2, msm_ids, msm_ids2;
+        msm_buckets, msm_chunks, msm_windows, msm_partials, msm_flags, st_coeffs, msm_cnt, msm_cnt2, msm_ids, msm_ids2,
+        msm_comb_pts, msm_comb_lins;
     bool timing = false;
     bool default_params = false;   // created from the built-in (unpinned) blob
     // batches up to these sizes take the cooperative (waves-per-signature) kernel: measured crossovers without /
@@ -80,6 +82,7 @@ struct ssa_ctx {
     size_t coop_max_n = 7680, coop_max_n_torsion = 10496;   // lane kernels: 3.5 / 5.4 ms flat up to 2^15 (round 2, window asm)
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;
+    std::vector<struct ssa_keyset *> keysets;   // live key sets of this context (orphaned, not leaked, by ssa_ctx_destroy)
 };
 
 static inline unsigned grid_for(size_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
@@ -180,37 +183,66 @@ struct PinnedRange {
     }
 };
 struct PipelinedInputs {
-    PinnedRange r_sigs, r_pks, r_msgs, r_inf, r_off;
+    // every caller range that a queued copy may still read or write is pinned HERE, so that the destructor below can
+    // drain the streams before any of them is unregistered (members are destroyed after the destructor body has run)
+    PinnedRange r_sigs, r_pks, r_msgs, r_inf, r_off, r_coeffs, r_status;
     StagedInputs s;     // device copies (context staging buffers)
+    ssa_ctx *armed = nullptr;   // set with the first enqueue; cleared by done() once the call has synchronised
+    void done() { armed = nullptr; }
+    ~PipelinedInputs() {
+        // an error return after the first enqueue: copies out of (into) the caller's memory and hash launches that
+        // write ctx->ws_h may still be in flight -- wait for them before the ranges are unpinned and the caller
+        // gets its buffers back
+        if (!armed) return;
+        (void)hipStreamSynchronize(armed->copy_stream);
+        for (auto &hs : armed->hash_stream) (void)hipStreamSynchronize(hs);
+        (void)hipStreamSynchronize(armed->stream);
+    }
 };
+
+// debug hook of the error-path tests: SSA_FAULT_AFTER_CHUNK=k makes the pipelined upload fail (SSA_ERR_HIP) after
+// chunk k has been enqueued
+static inline int pipeline_fault_chunk() {
+    const char *e = std::getenv("SSA_FAULT_AFTER_CHUNK");
+    return e ? std::atoi(e) : -1;
+}
 
 // Uploads of a large host-buffer batch in chunks on the copy stream; the challenge hashes of chunk c start as soon as
 // chunk c has arrived (they are 27 % of the per-signature work, 62 % of the MSM form), alternating between two
 // streams -- a lane hashes for ~4 ms and a launch's tail would otherwise idle most of the chip once per chunk.
-// On return ctx->stream waits for all of it: whatever the caller enqueues next sees the inputs and ctx->ws_h.
+// Ordering: the side streams first wait for everything already queued on ctx->stream (an earlier asynchronous
+// *_device call may still read ws_h or the staging buffers this call overwrites), and on return ctx->stream waits for
+// all of it: whatever the caller enqueues next sees the inputs and ctx->ws_h.
 // *used == false: the ranges could not be pinned (e.g. a read-only mapping) and nothing was enqueued.
 static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                                         const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
                                         size_t n, PipelinedInputs &pin, bool *used) {
     *used = false;
+    // arguments first: nothing is pinned or enqueued for a call that is going to be refused
     const size_t mb = msgs_bytes(msg_off, msg_stride, msg_len, n);
+    if (mb && !msgs) return SSA_ERR_ARG;
+    if (msg_off)
+        for (size_t i = 0; i < n; i++)
+            if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > 0xffffffffull) return SSA_ERR_ARG;
     if (!pin.r_sigs.pin(sigs, n * 81) || !pin.r_pks.pin(pks, n * 96) || !pin.r_msgs.pin(msgs, mb) ||
         !pin.r_inf.pin(pk_inf, n) || !pin.r_off.pin(msg_off, msg_off ? (n + 1) * sizeof(uint64_t) : 0))
         return 0;
     *used = true;
     if (ctx->st_sigs.reserve(n * 81) || ctx->st_pks.reserve(n * 96) || ctx->st_msgs.reserve(mb + 16) ||
-        ctx->ws_h.reserve(n * 4 * sizeof(u64)))
+        ctx->ws_h.reserve(n * 4 * sizeof(u64)) || (msg_off && ctx->st_off.reserve((n + 1) * sizeof(uint64_t))) ||
+        (pk_inf && ctx->st_inf.reserve(n)))
         return SSA_ERR_HIP;
+    HIP_TRY(hipEventRecord(ctx->pipe_start, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_start, 0));
+    for (auto &hs : ctx->hash_stream) HIP_TRY(hipStreamWaitEvent(hs, ctx->pipe_start, 0));
+    pin.armed = ctx;
+    const int fault_chunk = pipeline_fault_chunk();
     const u64 *d_off = nullptr;
     if (msg_off) {
-        for (size_t i = 0; i < n; i++)
-            if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > 0xffffffffull) return SSA_ERR_ARG;
-        if (ctx->st_off.reserve((n + 1) * sizeof(uint64_t))) return SSA_ERR_HIP;
         HIP_TRY(hipMemcpyAsync(ctx->st_off.p, msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy_stream));
         d_off = (const u64 *)ctx->st_off.p;
     }
     if (pk_inf) {
-        if (ctx->st_inf.reserve(n)) return SSA_ERR_HIP;
         HIP_TRY(hipMemcpyAsync(ctx->st_inf.p, pk_inf, n, hipMemcpyHostToDevice, ctx->copy_stream));
         pin.s.inf = (const u8 *)ctx->st_inf.p;
     }
@@ -234,6 +266,7 @@ static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const
             return rc;
         HIP_TRY(hipEventRecord(ctx->hash_done[c], hs));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->hash_done[c], 0));
+        if ((int)c == fault_chunk) return SSA_ERR_HIP;   // injected (tests)
     }
     pin.s.sigs = d_sigs;
     pin.s.pks = d_pks;
@@ -246,9 +279,3 @@ static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const
 int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
                               const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n);
 
-// defined in ssa_msm.hip: one shard's partial sums of the MSM-form batch (host buffers in, 24 words out), and the
-// combination of k shards on one device (returns a status)
-int ssa_internal_msm_partial(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
-                             const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
-                             const uint8_t *coeffs, uint64_t out24[24]);
-int ssa_internal_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k);

@@ -120,7 +120,7 @@ SSA_DEV void hash_message_lane(u64 *A, u64 *B, const DevParams *__restrict__ prm
 
 // ------------------------------------------------------------------------------------------
 #ifndef SSA_NO_KERNELS
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)    // four waves per SIMD: 128 VGPRs (the S-box blocks own v72..v127)
 ssa_k_hash(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs,
            const u8 *__restrict__ pks, MsgView mv, size_t n, u64 *__restrict__ h_out,
            u8 *__restrict__ digest_out, const u32 *__restrict__ key_idx, u32 n_keys) {
@@ -994,6 +994,30 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
     }
     if (op == 6) {
         po[0] = fp_canon(fp_inv(pa[0]));
+        return;
+    }
+    if (op == 18) {   // the Rescue S-boxes on RAW loose values: a = (x, y) -> x^7, y^7, x^(1/7), y^(1/7), asm flags
+        u64 x = pa[0], y = pa[1];
+        sbox2(x, y);
+        po[0] = fp_canon(x);
+        po[1] = fp_canon(y);
+        x = pa[0];
+        y = pa[1];
+        inv_sbox2(x, y);
+        po[2] = fp_canon(x);
+        po[3] = fp_canon(y);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SSA_NO_FP_CHAIN_ASM)
+        x = pa[0];
+        y = pa[1];
+        po[4] = sbox2_asm(x, y);          // non-zero: this lane's reduction met the rare borrow (the wrappers above
+        if (po[4] && (x != pa[0] || y != pa[1])) po[4] = 0xbad;   //   recomputed it); the inputs must come back
+        x = pa[0];
+        y = pa[1];
+        po[5] = inv_sbox2_asm(x, y);
+        if (po[5] && (x != pa[0] || y != pa[1])) po[5] = 0xbad;
+#else
+        po[4] = po[5] = 0;
+#endif
         return;
     }
     if (op <= 2) {

@@ -574,11 +574,14 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
 
 // One shard of a batch that spans several devices: stage the host buffers, run the MSM pipeline, return the shard's
 // 24-word partial record (left-hand point, sum s_i e_i, malformed flag) in host memory.
-int ssa_internal_msm_partial(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
-                             const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
-                             const uint8_t *coeffs, uint64_t out24[24]) {
+extern "C" int ssa_verify_batch_msm_partial(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                            const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
+                                            size_t msg_len, size_t n, const uint8_t *coeffs,
+                                            uint64_t out24[SSA_MSM_PARTIAL_WORDS]) {
+    if (!ctx || !out24 || (n && (!sigs || !pks))) return SSA_ERR_ARG;
+    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    std::memset(out24, 0, 24 * sizeof(uint64_t));
+    std::memset(out24, 0, SSA_MSM_PARTIAL_WORDS * sizeof(uint64_t));
     if (n == 0) return 0;
     StagedInputs s;
     const void *p;
@@ -595,40 +598,73 @@ int ssa_internal_msm_partial(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *p
     if (coeffs) {
         if (int rc = stage_up(ctx, ctx->st_coeffs, coeffs, n * 32, &p)) return rc;
     }
-    if (ctx->st_aux2.reserve(24 * sizeof(u64))) return SSA_ERR_HIP;
+    if (ctx->st_aux2.reserve(SSA_MSM_PARTIAL_WORDS * sizeof(u64))) return SSA_ERR_HIP;
     if (int rc = msm_run(ctx, s.sigs, s.pks, s.inf, s.msgs, s.off, msg_stride, msg_len, n, (const u8 *)p, 32, nullptr,
                          (u64 *)ctx->st_aux2.p))
         return rc;
-    HIP_TRY(hipMemcpyAsync(out24, ctx->st_aux2.p, 24 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out24, ctx->st_aux2.p, SSA_MSM_PARTIAL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
-// Device 0 adds the shards up: one Jacobian addition per shard, the scalars mod q, [lin]G from the comb table and the
-// x-only comparison (src/batch.rs:98-100,123-129) -- msm_k_finish with no doublings between its "windows".
-int ssa_internal_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k) {
+// the device-buffer form: what one rank of a process-per-GPU job calls on its shard (the records then travel by
+// all-gather, 24 words per rank)
+extern "C" int ssa_verify_batch_msm_partial_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
+                                                   const uint8_t *d_pk_inf, const uint8_t *d_msgs,
+                                                   const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                                                   const uint8_t *d_coeffs, uint32_t coeff_bytes,
+                                                   uint64_t *d_partial_out) {
+    if (!d_partial_out) return SSA_ERR_ARG;
+    return msm_run(ctx, d_sigs, d_pks, d_pk_inf, d_msgs, d_msg_off, msg_stride, msg_len, n, d_coeffs, coeff_bytes, nullptr,
+                   (u64 *)d_partial_out);
+}
+
+namespace ssa {
+// k partial records (24-word stride) -> the layout msm_k_finish reads: k points of 18 words, k scalars of 4 words, and
+// the OR of the malformed flags
+__global__ void msm_k_unpack_parts(const u64 *__restrict__ parts, u32 k, u64 *__restrict__ pts, u64 *__restrict__ lins,
+                                   u32 *__restrict__ malformed) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * 24u) return;
+    const u32 j = t / 24u, w = t % 24u;
+    const u64 v = parts[t];
+    if (w < 18) pts[18u * j + w] = v;
+    else if (w < 22) lins[4u * j + (w - 18u)] = v;
+    else if (w == 22 && v != 0) atomicOr(malformed, 1u);
+}
+}  // namespace ssa
+
+// The shards added up on one device: one Jacobian addition per shard, the scalars mod q, [lin]G from the comb table and
+// the x-only comparison (src/batch.rs:98-100,123-129) -- msm_k_finish with no doublings between its "windows".
+extern "C" int ssa_msm_combine_device(ssa_ctx *ctx, const uint64_t *d_parts24, size_t k, uint32_t *d_verdict_out) {
+    if (!ctx || !d_parts24 || !d_verdict_out || k == 0 || k > 4096) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    for (size_t j = 0; j < k; j++)
-        if (parts24[24 * j + 22]) return SSA_MALFORMED;
-    std::vector<uint64_t> pts(18 * k), lins(4 * k);
-    for (size_t j = 0; j < k; j++) {
-        std::memcpy(&pts[18 * j], parts24 + 24 * j, 18 * sizeof(uint64_t));
-        std::memcpy(&lins[4 * j], parts24 + 24 * j + 18, 4 * sizeof(uint64_t));
-    }
-    const void *d_pts, *d_lins;
-    if (int rc = stage_up(ctx, ctx->st_aux, pts.data(), pts.size() * 8, &d_pts)) return rc;
-    if (int rc = stage_up(ctx, ctx->st_aux2, lins.data(), lins.size() * 8, &d_lins)) return rc;
-    if (ctx->msm_flags.reserve(64)) return SSA_ERR_HIP;
+    if (ctx->msm_comb_pts.reserve(18 * k * sizeof(u64)) || ctx->msm_comb_lins.reserve(4 * k * sizeof(u64)) ||
+        ctx->msm_flags.reserve(64))
+        return SSA_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(msm_k_unpack_parts, dim3(grid_for(k * 24, 256)), dim3(256), 0, ctx->stream, (const u64 *)d_parts24,
+                       (u32)k, (u64 *)ctx->msm_comb_pts.p, (u64 *)ctx->msm_comb_lins.p, (u32 *)ctx->msm_flags.p);
+    HIP_TRY(hipGetLastError());
     MsmShape sh;
     sh.c = 0;
     sh.windows = (u32)k;
     sh.buckets = 1;
     sh.chunks = 1;
+    return timed_launch(ctx, "msm_combine", [&] {
+        hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(128), 0, ctx->stream, (const u64 *)ctx->msm_comb_pts.p, sh,
+                           (const u64 *)ctx->msm_comb_lins.p, (u32)k, (const u64 *)ctx->d_gtab,
+                           (const u32 *)ctx->msm_flags.p, d_verdict_out, (u64 *)nullptr);
+    });
+}
+
+extern "C" int ssa_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k) {
+    if (!ctx || !parts24 || k == 0 || k > 4096) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const void *d_parts;
+    if (int rc = stage_up(ctx, ctx->st_aux, parts24, k * SSA_MSM_PARTIAL_WORDS * sizeof(uint64_t), &d_parts)) return rc;
     uint32_t *d_verdict = (uint32_t *)((char *)ctx->ws_fail.p + 32);
-    hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(128), 0, ctx->stream, (const u64 *)d_pts, sh, (const u64 *)d_lins,
-                       (u32)k, (const u64 *)ctx->d_gtab, (const u32 *)ctx->msm_flags.p, d_verdict, (u64 *)nullptr);
-    HIP_TRY(hipGetLastError());
+    if (int rc = ssa_msm_combine_device(ctx, (const uint64_t *)d_parts, k, d_verdict)) return rc;
     uint32_t v = SSA_MALFORMED;
     HIP_TRY(hipMemcpyAsync(&v, d_verdict, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -646,19 +682,21 @@ extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uin
     // coefficients drawn on the device from a ChaCha20 stream keyed with getrandom(2)
     if (n >= ctx->pipeline_min_n && ctx->pipeline_chunks > 1) {
         // large batch: uploads pinned in place and chunked, the hashes (62 % of this form) run behind them
-        PipelinedInputs pin;
-        PinnedRange r_coeffs;
+        PipelinedInputs pin;      // its destructor drains the side streams on every error return below
         bool used = false;
-        if (r_coeffs.pin(coeffs, coeffs ? n * 32 : 0)) {
-            const void *pc = nullptr;
-            if (coeffs) {
-                if (ctx->st_coeffs.reserve(n * 32)) return SSA_ERR_HIP;
-                HIP_TRY(hipMemcpyAsync(ctx->st_coeffs.p, coeffs, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
-                pc = ctx->st_coeffs.p;     // ordered before the chunk copies whose events ctx->stream waits for
-            }
+        if (pin.r_coeffs.pin(coeffs, coeffs ? n * 32 : 0)) {
+            if (coeffs && ctx->st_coeffs.reserve(n * 32)) return SSA_ERR_HIP;
             if (int rc = pipelined_upload_hash(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, pin, &used))
                 return rc;
             if (used) {
+                const void *pc = nullptr;
+                if (coeffs) {
+                    // behind the chunk copies on the copy stream; ctx->stream waits for this copy explicitly
+                    HIP_TRY(hipMemcpyAsync(ctx->st_coeffs.p, coeffs, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+                    HIP_TRY(hipEventRecord(ctx->pipe_start, ctx->copy_stream));
+                    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->pipe_start, 0));
+                    pc = ctx->st_coeffs.p;
+                }
                 uint32_t *d_verdict = (uint32_t *)((char *)ctx->ws_fail.p + 32);
                 if (int rc = msm_run(ctx, pin.s.sigs, pin.s.pks, pin.s.inf, pin.s.msgs, pin.s.off, msg_stride, msg_len, n,
                                      (const u8 *)pc, 32, d_verdict, nullptr, true))
@@ -666,6 +704,7 @@ extern "C" int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uin
                 uint32_t v = SSA_MALFORMED;
                 HIP_TRY(hipMemcpyAsync(&v, d_verdict, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
                 HIP_TRY(hipStreamSynchronize(ctx->stream));
+                pin.done();
                 return (int)v;
             }
         }

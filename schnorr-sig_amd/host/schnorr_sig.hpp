@@ -45,6 +45,10 @@ using Rng = std::function<void(uint8_t *, size_t)>;  // fills a buffer with rand
 class Context {
   public:
     explicit Context(int device = 0, const void *params = nullptr, size_t params_len = 0) {
+        // a library from another revision of the header links just as well and reads its arguments shifted
+        if (ssa_abi_version() != SSA_ABI_VERSION)
+            throw std::runtime_error("schnorr_sig_amd: library ABI version " + std::to_string(ssa_abi_version()) +
+                                     ", header " + std::to_string(SSA_ABI_VERSION));
         int rc = ssa_ctx_create(&ctx_, device, params, params_len);
         if (rc != 0) throw std::runtime_error(std::string("ssa_ctx_create: ") + ssa_strerror(rc));
     }

@@ -31,7 +31,7 @@ def batch_verdict(total_fail):
 def gather_status(local_status_tensor, n, rank, world, dist):
     """All-gather of per-shard status bytes into the full n-vector (ragged shards padded to the max)."""
     import torch
-    if dist is None or world == 1:
+    if dist is None:
         return local_status_tensor
     width = (n + world - 1) // world
     pad = torch.full((width,), 255, dtype=local_status_tensor.dtype, device=local_status_tensor.device)
@@ -53,7 +53,7 @@ def scatter_rows(full, n, row_bytes, rank, world, dist, device=None, src=0):
     (views, no staging copy); ragged shards are padded to the largest."""
     import torch
     lo, hi = shard_range(n, rank, world)
-    if dist is None or world == 1:
+    if dist is None:        # no process group; with one the collective runs even at world size 1 (RCCL rehearsal)
         return full[lo:hi]
     width = (n + world - 1) // world
     dev = device if device is not None else (full.device if full is not None else "cpu")
@@ -79,9 +79,35 @@ def broadcast_rows(full, n, row_bytes, rank, world, dist, device=None, src=0):
     scatter_rows; kept as an option and timed beside it."""
     import torch
     lo, hi = shard_range(n, rank, world)
-    if dist is None or world == 1:
+    if dist is None:
         return full[lo:hi]
     dev = device if device is not None else (full.device if full is not None else "cpu")
     buf = full if rank == src else torch.empty((n, row_bytes), dtype=torch.uint8, device=dev)
     dist.broadcast(buf, src=src)
     return buf[lo:hi]
+
+
+MSM_PARTIAL_WORDS = 24   # SSA_MSM_PARTIAL_WORDS of include/schnorr_sig_amd.h
+
+
+def gather_msm_partials(local_record, world, dist):
+    """All-gather of the ranks' MSM-form shard records (int64[24] each, include/schnorr_sig_amd.h:
+    ssa_verify_batch_msm_partial_device): 24 words per rank are the only traffic of the MSM-form verify_batch across
+    processes (reference src/batch.rs:98-129: every shard contributes one point and one scalar).  Returns the
+    (world, 24) tensor on every rank, in rank order; dist=None: the single record as a (1, 24) tensor."""
+    import torch
+    rec = local_record.reshape(MSM_PARTIAL_WORDS)
+    if dist is None:
+        return rec.reshape(1, MSM_PARTIAL_WORDS).clone()
+    out = torch.empty(world * MSM_PARTIAL_WORDS, dtype=rec.dtype, device=rec.device)   # flat: gloo insists
+    dist.all_gather_into_tensor(out, rec.contiguous())
+    return out.reshape(world, MSM_PARTIAL_WORDS)
+
+
+def msm_verdict(local_record, world, dist, combine):
+    """verify_batch's single verdict for a batch sharded over `world` ranks in the MSM form: gather the shard records,
+    then `combine(records)` -- ssa_msm_combine[_device] on this rank's context: one point addition per shard, [sum]G,
+    x-only compare -- on EVERY rank (each holds all the records, so no broadcast of the verdict is needed and the ranks
+    cannot disagree: the combination is deterministic).  Returns (verdict, records)."""
+    records = gather_msm_partials(local_record, world, dist)
+    return combine(records), records

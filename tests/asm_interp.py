@@ -16,13 +16,13 @@ def extract_blocks(path):
     SSA_DEV function of the generated file that contains an asm statement"""
     txt = open(path).read()
     out = {}
-    for m in re.finditer(r"SSA_DEV void (\w+)\(.*?\) \{\n(.*?)\n\}\n", txt, re.S):
+    for m in re.finditer(r"SSA_DEV (?:void|u32) (\w+)\(.*?\) \{\n(.*?)\n\}\n", txt, re.S):
         name, body = m.group(1), m.group(2)
         am = re.search(r"asm(?: volatile)?\(\n(.*?)\n        : (.*?)\n        :(.*?)\n        : \"", body, re.S)
         if not am:
             continue
         lines = [ln.strip().strip('"').replace("\\n\\t", "") for ln in am.group(1).split("\n") if ln.strip()]
-        outs = re.findall(r"\[(\w+)\] \"[=+]v\"", am.group(2))
+        outs = re.findall(r"\[(\w+)\] \"[=+]&?v\"", am.group(2))
         ins = {}
         for nm, half, arr, idx in re.findall(r"\[(\w+)\] \"v\"\((lo32|hi32)\((\w+)\[(\d+)\]\)\)", am.group(3)):
             ins[nm] = (half, arr, int(idx))
@@ -131,8 +131,16 @@ class Lane:
                 if not getattr(self, "exec_bit", 1):
                     pc = labels[a[0]]
             elif op == "s_mov_b64":
-                assert a[0] == "exec"
-                self.exec_bit = self.exec_saved
+                if a[0] == "exec":
+                    self.exec_bit = self.exec_saved
+                else:                       # a mask pair set to a constant by the scalar unit
+                    kd = self._key(a[0])
+                    self.s[kd] = 1 if int(a[1], 0) & 1 else 0
+                    self.written_at[kd] = -100
+            elif op == "s_or_b64":
+                kd, ka, kb = self._key(a[0]), self._key(a[1]), self._key(a[2])
+                self.s[kd] = self.s.get(ka, 0) | self.s.get(kb, 0)
+                self.written_at[kd] = -100
             elif op == "s_branch":
                 pc = labels[a[0]]
             elif op == "s_and_b64":

@@ -21,26 +21,81 @@ F6_INC = os.path.join(os.path.dirname(INC), "fp6_asm.inc")
 
 
 def run(txt_blocks, fn, x, y):
+    """-> (x', y', flag): flag != 0 means a reduction met its rare borrow and x', y' are to be recomputed"""
     lines, outs, _ = txt_blocks[fn]
     env = {"%[x0]": x & M32, "%[x1]": x >> 32, "%[y0]": y & M32, "%[y1]": y >> 32, "%[n]": 5}
     lane = ai.Lane(env, dummy_pairs=("s[24:25]",))
     e = lane.run(lines)
-    return e["%[x0]"] | (e["%[x1]"] << 32), e["%[y0]"] | (e["%[y1]"] << 32)
+    return e["%[x0]"] | (e["%[x1]"] << 32), e["%[y0]"] | (e["%[y1]"] << 32), e["%[fl]"]
 
 
 def test_generated_sbox_asm_on_the_cpu():
     txt = ai.extract_blocks(INC)
+    assert set(txt) == {"fp_sqr2_n_asm", "inv_sbox2_asm", "sbox2_asm"}
     rnd = random.Random(5)
     e_inv = 10540996611094048183          # 7^-1 mod (p - 1)
     vals = [0, 1, P - 1, P, P + 1, 2**64 - 1, 2**32, 2**32 - 1, 2**63, 2**64 - 2**32] + [rnd.randrange(2**64) for _ in range(30)]
+    flagged = 0
     for i, a in enumerate(vals):
         b = vals[(i * 7 + 3) % len(vals)]
-        rx, ry = run(txt, "inv_sbox2_asm", a, b)
-        assert rx % P == pow(a, e_inv, P) and ry % P == pow(b, e_inv, P), (hex(a), hex(b))
-        rx, ry = run(txt, "sbox2_asm", a, b)
-        assert rx % P == pow(a, 7, P) and ry % P == pow(b, 7, P), (hex(a), hex(b))
-        rx, ry = run(txt, "fp_sqr2_n_asm", a, b)     # n = 5 in the interpreter
-        assert rx % P == pow(a, 32, P) and ry % P == pow(b, 32, P)
+        for fn, want in (("inv_sbox2_asm", lambda v: pow(v, e_inv, P)), ("sbox2_asm", lambda v: pow(v, 7, P)),
+                         ("fp_sqr2_n_asm", lambda v: pow(v, 32, P))):      # n = 5 in the interpreter
+            rx, ry, fl = run(txt, fn, a, b)
+            flagged += bool(fl)
+            # a flagged lane is recomputed by the caller; an unflagged one must be right
+            assert fl or (rx % P == want(a) and ry % P == want(b)), (fn, hex(a), hex(b))
+    assert flagged <= 6          # only the hand-picked edge values can get there (2^32 * 2^32 = 2^64, ...)
+
+
+def test_sbox_asm_reports_the_rare_borrow():
+    """a = k 2^48: a^2 = k^2 2^96, so lo = 0, hi.lo = 0, hi.hi = k^2 -- the reduction X - h1 borrows with no carry to
+    cancel it.  The block must flag such a lane (in either chain) instead of returning a wrong value, and must not
+    flag the neighbour chain's lane-mate for it... it does: the flag is per lane, for both values."""
+    txt = ai.extract_blocks(INC)
+    for k in (1, 3, 0xffff):
+        a = k << 48
+        for fn in ("inv_sbox2_asm", "sbox2_asm", "fp_sqr2_n_asm"):
+            assert run(txt, fn, a, 5)[2] == 1 and run(txt, fn, 5, a)[2] == 1, (fn, k)
+            assert run(txt, fn, 5, 7)[2] == 0
+        for fn in ("inv_sbox2_asm", "sbox2_asm"):     # a flagged lane gets its inputs back: the caller recomputes from them
+            assert run(txt, fn, a, 5) == (a, 5, 1) and run(txt, fn, 6, a) == (6, a, 1), (fn, k)
+
+
+def test_reduction_tail_is_exact_or_flagged():
+    """the three-instruction tail of the generated reduction on (lo, hi) pairs at every boundary: with
+    V = lo + EPS * hi.lo - hi.hi it must deliver V mod 2^64 + (carry ? EPS : 0) -- congruent to V, no wrap -- or raise
+    the sticky flag, and the flag exactly when the true value is negative (no carry, X < hi.hi)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_fp_chain_asm as g
+    regs = g.regs(0)
+    lines = g.schedule([g.reduce_tail(0)])
+    rnd = random.Random(77)
+    EPS = 2**32 - 1
+    h_vals = [0, 1, 2, EPS, EPS - 1, 2**31] + [rnd.randrange(2**32) for _ in range(6)]
+    n_flag = n_carry = 0
+    for h0 in h_vals:
+        for h1 in h_vals:
+            base = (2**64 - EPS * h0) % 2**64
+            los = {0, 1, h1, max(h1 - 1, 0), h1 + 1, 2**64 - 1, 2**64 - 2, base, (base - 1) % 2**64, (base + 1) % 2**64,
+                   (base + h1) % 2**64, (base + h1 - 1) % 2**64, (base + h1 + 1) % 2**64, 2**32 - 1, 2**32}
+            los |= {rnd.randrange(2**64) for _ in range(4)}
+            for lo in los:
+                lane = ai.Lane({}, dummy_pairs=("s[24:25]",))
+                lane.v[regs["T"]], lane.v[regs["T"] + 1] = lo & M32, lo >> 32
+                lane.v[regs["H"]], lane.v[regs["H"] + 1] = h0, h1
+                lane.s[g.STICKY] = 0
+                lane.run(lines)
+                x = lane.v[regs["X"]] | (lane.v[regs["X"] + 1] << 32)
+                full = lo + EPS * h0
+                carry, X = full >> 64, full & M64
+                assert carry <= 1
+                negative = carry == 0 and X < h1
+                assert lane.s[g.STICKY] == int(negative), (hex(lo), hex(h0), hex(h1))
+                n_flag += negative
+                n_carry += carry
+                if not negative:
+                    assert x == X + carry * EPS - h1 and x % P == (lo + (h0 << 64) + (h1 << 96)) % P, (hex(lo), hex(h0), hex(h1))
+    assert n_flag >= 20 and n_carry > 500
 
 
 def _f6_mulmod(u, v):
@@ -358,24 +413,23 @@ def test_doubling_asm_declares_its_registers_and_kernels_leave_room():
             assert m.group(2) and int(m.group(2).split(",")[0]) <= 256, m.group(3)
 
 
-def test_generated_file_is_up_to_date():
-    """fp_chain_asm.inc is what tools/gen_fp_chain_asm.py generates (no hand edits)"""
+def test_generated_files_are_up_to_date():
+    """fp_chain_asm.inc, jac_asm.inc and fp6_asm.inc are what their generators produce (no hand edits, no stale
+    generator).  The text is generated IN MEMORY and compared: a test must not write tracked sources (a rewrite bumps
+    their mtimes, and a stale generator would overwrite the committed file before the assertion fires)."""
     import importlib.util
     import io
     from contextlib import redirect_stdout
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    before = open(INC).read()
-    spec = importlib.util.spec_from_file_location("gen_fp_chain_asm", os.path.join(root, "tools", "gen_fp_chain_asm.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    with redirect_stdout(io.StringIO()):
-        mod.main()
-    assert open(INC).read() == before
-    before = open(JAC_INC).read()
-    spec = importlib.util.spec_from_file_location("gen_jac_asm", os.path.join(root, "tools", "gen_jac_asm.py"))
-    mod = importlib.util.module_from_spec(spec)
     sys.path.insert(0, os.path.join(root, "tools"))
-    spec.loader.exec_module(mod)
-    with redirect_stdout(io.StringIO()):
-        mod.main()
-    assert open(JAC_INC).read() == before
+    for tool, inc in (("gen_fp_chain_asm", "fp_chain_asm.inc"), ("gen_jac_asm", "jac_asm.inc"), ("gen_f6_asm", "fp6_asm.inc")):
+        path = os.path.join(root, "schnorr-sig_amd", "csrc", inc)
+        mtime = os.path.getmtime(path)
+        spec = importlib.util.spec_from_file_location(tool, os.path.join(root, "tools", tool + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        with redirect_stdout(io.StringIO()):
+            text = mod.generate()
+        assert os.path.abspath(mod.OUT_PATH) == os.path.abspath(path)
+        assert text == open(path).read(), "%s is not what tools/%s.py generates" % (inc, tool)
+        assert os.path.getmtime(path) == mtime, "the freshness test wrote " + inc

@@ -1,0 +1,359 @@
+"""GPU tests added in round 3 (all through the C ABI):
+ * the process-group path of bench.py on ONE GPU: a forced one-rank `nccl` group, so that scatter / broadcast /
+   all-reduce / all-gather of the MSM records / max-over-ranks run through RCCL on device tensors before the
+   driver's multi-GPU node ever sees this code (BASELINE.json configs[3]);
+ * the MSM-form verdict across processes through the PUBLIC partial/combine entry points (reference
+   src/batch.rs:98-129: one point and one scalar per shard, one addition per shard, one compare);
+ * stream ordering and error paths of the pipelined host-buffer upload;
+ * a key set that outlives its engine; the debug probes refuse a zero doubling count."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q = 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
+
+
+def make_scalars(rng, n):
+    s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    s[:, 31] &= 0x3F
+    s[:, 0] |= 1
+    return s
+
+
+def honest(engine, rng, n, msg_len=80):
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, msg_len), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    return sigs, pks, msgs
+
+
+def coeffs32(rng, n):
+    c = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    c[:, 31] &= 0x3F
+    return c
+
+
+# ---------------------------------------------------------------- RCCL under bench.py on one GPU
+def _bench(args, timeout=900):
+    """bench.py as a FRESH child process (never an exec of this process, which has touched the GPU)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_collectives_run_through_rccl_on_one_rank():
+    """`--force-dist`: a world-size-1 nccl group; every collective of the N > 1 run executes on device tensors."""
+    out = _bench(["--gpus", "1", "--force-dist", "--batch", "65536", "--steps", "2", "--warmup", "1",
+                  "--strong-total", "131072", "--cpu-sample", "256", "--corrupt", "0.01"])
+    assert out["n_gpus"] == 1 and out["config"]["backend"] == "nccl"
+    assert out["config"]["process_group"].startswith("forced one-rank")
+    assert out["config"]["workload"].startswith("config5: 2^16 random-keypair signatures per GPU, 1 % corrupted")
+    assert out["config"]["signatures_per_gpu"] == 65536
+    assert out["all_verdicts_as_expected"] is True and out["rejected"] == 655     # all-reduce of the counts (RCCL)
+    c4 = out["config4_strong"]
+    assert "error" not in c4, c4
+    assert c4["scatter_ms"] is not None and c4["broadcast_ms"] is not None         # dist.scatter / dist.broadcast
+    assert c4["signatures_total"] == 131072 and c4["rejected"] == 0
+    msm = out["verify_batch_msm_form"]
+    assert msm["combined_over_ranks"] is True                                       # all-gather of the 24-word records
+    assert msm["verdict"] == msm["expected_verdict"] == 2
+    assert msm["stages_ms"]["msm_combine"] > 0
+    assert out["cpu_baseline"]["agrees_with_gpu"] is True
+    assert out["cpu_baseline"]["all_threads_msm_form"]["verify_batch_msm_form_verdict"] in (0, 2)
+    assert out["roofline"]["work_executed"] > out["roofline"]["work_per_unit"] * 0.9
+
+
+def test_bench_workload_label_follows_the_batch():
+    out = _bench(["--gpus", "1", "--batch", "4096", "--steps", "1", "--warmup", "0", "--skip-torsion-leg",
+                  "--no-cpu-baseline"])
+    assert out["config"]["workload"].startswith("config3: 2^12 random-keypair signatures per GPU,")
+    assert out["config"]["backend"] is None and out["all_verdicts_as_expected"] is True
+
+
+# ---------------------------------------------------------------- MSM verdict across processes: public API
+def _shards(n, k):
+    from schnorr_sig_amd.sharding import shard_range
+    return [shard_range(n, r, k) for r in range(k)]
+
+
+@pytest.mark.parametrize("n", [2, 3, 64, 1000, 20000])
+def test_msm_partial_and_combine_public_api(engine, oracle, n):
+    """Three contexts on device 0, each reducing its contiguous shard to one record through
+    ssa_verify_batch_msm_partial[_device]; ssa_msm_combine[_device] of the three records must equal
+    ssa_verify_batch_msm on the whole batch and the oracle's src/batch.rs restatement -- honest, one corrupted
+    signature, an identity key, an undecodable signature."""
+    import torch
+    import schnorr_sig_amd as ssa
+    rng = np.random.default_rng(3000 + n)
+    sigs, pks, msgs = honest(engine, rng, n)
+    co = coeffs32(rng, n)
+    engines = [ssa.Engine(0) for _ in range(3)]
+    dev = torch.device("cuda", 0)
+
+    def records_host(sg, inf=None):
+        recs = []
+        for e, (lo, hi) in zip(engines, _shards(n, 3)):
+            recs.append(e.verify_batch_msm_partial(sg[lo:hi], pks[lo:hi], msgs[lo:hi], coeffs=co[lo:hi],
+                                                   pk_inf=None if inf is None else inf[lo:hi]))
+        return np.stack(recs)
+
+    def records_device(sg):
+        recs = torch.zeros((3, 24), dtype=torch.int64, device=dev)
+        keep = []
+        for r, (e, (lo, hi)) in enumerate(zip(engines, _shards(n, 3))):
+            cnt = hi - lo
+            ds, dp, dm, dc = (torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev) for a in (sg, pks, msgs, co))
+            keep.append((ds, dp, dm, dc))
+            e.verify_batch_msm_partial_device(ds.data_ptr() if cnt else 0, dp.data_ptr() if cnt else 0,
+                                              dm.data_ptr() if cnt else 0, cnt, 80, dc.data_ptr() if cnt else 0, 32,
+                                              recs[r].data_ptr())
+            e.sync()
+        return recs
+
+    try:
+        # honest
+        rec = records_host(sigs)
+        assert (rec[:, 22:] == 0).all()
+        assert engines[1].msm_combine(rec) == engine.verify_batch_msm(sigs, pks, msgs, coeffs=co) == 0
+        rec_d = records_device(sigs)
+        assert (rec_d.cpu().numpy().astype(np.uint64) == rec).all(), "device and host records differ"
+        verdict = torch.full((1,), 255, dtype=torch.int32, device=dev)
+        engines[0].msm_combine_device(rec_d.data_ptr(), 3, verdict.data_ptr())
+        engines[0].sync()
+        assert int(verdict.item()) == 0
+        # the order of the records does not matter (a sum); honest shards verify on their own (a sub-batch); a record
+        # whose scalar or point was tampered with on the way does not
+        assert engines[2].msm_combine(rec[::-1].copy()) == 0
+        assert engines[2].msm_combine(rec[:2].copy()) == 0
+        tam = rec.copy()
+        tam[0, 18] ^= np.uint64(1)
+        assert engines[2].msm_combine(tam) == 2
+        tam = rec.copy()
+        tam[0, :18], tam[1, :18] = rec[1, :18], rec[0, :18]                    # points swapped, scalars not: still the same sums
+        assert engines[2].msm_combine(tam) == 0
+        tam[0, 0] ^= np.uint64(2)
+        assert engines[2].msm_combine(tam) == 2
+        # one corrupted signature in the last shard
+        bad = sigs.copy()
+        bad[n - 1, 50] ^= 4
+        assert engines[0].msm_combine(records_host(bad)) == engine.verify_batch_msm(bad, pks, msgs, coeffs=co) == 2
+        # undecodable signature in the middle shard: the reference panics (src/batch.rs:104)
+        und = sigs.copy()
+        und[n // 2, 48] |= 2
+        rec_u = records_host(und)
+        assert rec_u[:, 22].sum() == 1
+        assert engines[0].msm_combine(rec_u) == engine.verify_batch_msm(und, pks, msgs, coeffs=co) == 3
+        # identity key (contributes nothing, src/batch.rs:106): the batch no longer verifies
+        inf = np.zeros(n, np.uint8)
+        inf[1] = 1
+        assert engines[0].msm_combine(records_host(sigs, inf)) == \
+            engine.verify_batch_msm(sigs, pks, msgs, coeffs=co, pk_inf=inf) == 2
+        if n <= 1000:
+            assert oracle.verify_batch_msm(sigs, pks, msgs, co) == 0 and oracle.verify_batch_msm(bad, pks, msgs, co) == 2
+            assert oracle.verify_batch_msm(und, pks, msgs, co) == 3
+            assert oracle.verify_batch_msm(sigs, pks, msgs, co, pk_inf=inf) == 2
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_msm_combine_rejects_bad_arguments(engine):
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        engine.msm_combine(np.zeros((0, 24), np.uint64))
+    # k empty shards: the identity on the left, [0]G on the right -> Ok, like the reference's empty batch
+    assert engine.msm_combine(np.zeros((2, 24), np.uint64)) == 0
+
+
+def test_sharding_msm_verdict_single_process(engine):
+    """schnorr_sig_amd.sharding.msm_verdict without a process group: the gather is the identity, the combination runs"""
+    import torch
+    from schnorr_sig_amd.sharding import msm_verdict
+    rng = np.random.default_rng(3100)
+    sigs, pks, msgs = honest(engine, rng, 50)
+    rec = torch.from_numpy(engine.verify_batch_msm_partial(sigs, pks, msgs).astype(np.int64))
+    v, recs = msm_verdict(rec, 1, None, lambda r: engine.msm_combine(r.numpy().astype(np.uint64)))
+    assert v == 0 and recs.shape == (1, 24)
+
+
+# ---------------------------------------------------------------- pipelined upload: ordering and error paths
+def test_async_device_verify_followed_by_pipelined_host_verify(engine, oracle):
+    """An asynchronous *_device call still reads ws_h / the tables while a host-buffer call with n >= 2^17 starts its
+    chunked upload on the side streams: the side streams must wait for the context's stream."""
+    import torch
+    rng = np.random.default_rng(3200)
+    n1, n2 = 1 << 18, (1 << 17) + 77
+    s1, p1, m1 = honest(engine, rng, n1)
+    bad1 = rng.permutation(n1)[:300]
+    s1[bad1, 55] ^= 8
+    s2, p2, m2 = honest(engine, rng, n2)
+    bad2 = rng.permutation(n2)[:200]
+    m2[bad2, 3] ^= 1
+    dev = torch.device("cuda", 0)
+    ds, dp, dm = (torch.from_numpy(a).to(dev) for a in (s1, p1, m1))
+    dst = torch.full((n1,), 255, dtype=torch.uint8, device=dev)
+    dnf = torch.zeros(1, dtype=torch.int64, device=dev)
+    engine.sync()
+    for _ in range(3):
+        engine.verify_many_device(ds.data_ptr(), dp.data_ptr(), dm.data_ptr(), n1, 80, dst.data_ptr(), dnf.data_ptr(),
+                                  mode="lane")
+        # no synchronisation here
+        st2, nf2 = engine.verify_many(s2, p2, m2, check_torsion=False, mode="lane")
+        engine.sync()
+        st1 = dst.cpu().numpy()
+        assert int(dnf.item()) == 300 and (st1[bad1] == 2).all() and int((st1 != 0).sum()) == 300
+        assert nf2 == 200 and (st2[bad2] == 2).all() and int((st2 != 0).sum()) == 200
+    samp = np.concatenate([bad1[:50], np.arange(0, n1, 4099)])
+    assert (st1[samp] == oracle.verify_many(s1[samp], p1[samp], m1[samp], check_torsion=False)).all()
+
+
+def test_pipelined_upload_error_paths(engine, oracle):
+    """An error after the first enqueue of the chunked upload (injected: SSA_FAULT_AFTER_CHUNK) must return an error
+    code with every stream drained -- the caller's arrays are unpinned and may be freed at once -- and the next call on
+    the context must be correct.  Bad message arguments are refused before anything is pinned or enqueued."""
+    rng = np.random.default_rng(3300)
+    n = (1 << 17) + 5
+    sigs, pks, msgs = honest(engine, rng, n)
+    sigs[7, 49] ^= 1
+    for chunk in ("0", "3", "7"):
+        os.environ["SSA_FAULT_AFTER_CHUNK"] = chunk
+        try:
+            with pytest.raises(RuntimeError, match="HIP runtime error"):
+                engine.verify_many(sigs, pks, msgs, check_torsion=False, mode="lane")
+            with pytest.raises(RuntimeError, match="HIP runtime error"):
+                engine.verify_batch_msm(sigs, pks, msgs, coeffs=coeffs32(rng, n))
+        finally:
+            del os.environ["SSA_FAULT_AFTER_CHUNK"]
+        # the arrays the failed call read are released and overwritten right away
+        scratch = sigs.copy()
+        scratch[:] = 0
+        del scratch
+        st, nf = engine.verify_many(sigs, pks, msgs, check_torsion=False, mode="lane")
+        assert nf == 1 and st[7] == 2 and int((st != 0).sum()) == 1
+    assert engine.verify_batch_msm(sigs, pks, msgs) == 2
+    # offsets that run backwards: SSA_ERR_ARG from the pipelined path too
+    off = np.arange(n + 1, dtype=np.uint64) * 80
+    off[5] = off[6] + 1
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        engine.verify_many(sigs, pks, msgs.reshape(-1), offsets=off, check_torsion=False, mode="lane")
+    samp = np.arange(0, 2048)
+    assert (st[samp] == oracle.verify_many(sigs[samp], pks[samp], msgs[samp], check_torsion=False)).all()
+
+
+# ---------------------------------------------------------------- lifetime and probe hygiene
+def test_keyset_may_outlive_its_engine():
+    import schnorr_sig_amd as ssa
+    eng = ssa.Engine(0)
+    rng = np.random.default_rng(3400)
+    sigs, pks, msgs = honest(eng, rng, 8)
+    ks = eng.keyset_create(pks, kind="ladder")
+    st, nf = eng.verify_many_indexed(ks, np.arange(8, dtype=np.uint32), sigs, msgs)
+    assert nf == 0
+    assert ks.engine is eng                      # the wrapper keeps the engine alive
+    eng.close()                                  # context destroyed first: the key set is orphaned, not dangling
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        eng2 = ssa.Engine(0)
+        try:
+            eng2.keyset_status(ks)
+        finally:
+            eng2.close()
+    ks.close()                                   # frees the host handle only; no use-after-free
+    ks.close()
+
+
+def test_debug_window_probe_refuses_zero_or_mixed_counts(engine):
+    a = np.zeros((64, 20), np.uint64)
+    b = np.zeros((64, 12), np.uint64)
+    a[:, 12] = 1
+    a[:, 19] = 0
+    for op in (15, 17):
+        with pytest.raises(RuntimeError, match="invalid argument"):
+            engine.debug_arith(op, a, b, 19)
+    a[:, 19] = 2
+    a[5, 19] = 3
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        engine.debug_arith(17, a, b, 19)
+
+
+def test_abi_version_matches_header():
+    import re
+    import schnorr_sig_amd as ssa
+    hdr = open(os.path.join(ROOT, "include", "schnorr_sig_amd.h")).read()
+    assert int(re.search(r"#define SSA_ABI_VERSION (\d+)", hdr).group(1)) == ssa.ABI_VERSION == ssa._lib.ssa_abi_version()
+
+
+# ---------------------------------------------------------------- the reference's own batch sizes, MSM form
+@pytest.mark.parametrize("n", [4, 16, 32, 64, 128, 500, 2047, 2048, 4095, 4096])
+def test_verify_batch_msm_at_the_reference_bench_sizes(engine, oracle, n):
+    """benches/schnorr.rs:78-96 batches (4..128 signatures) and the sizes around the window-width / small-batch
+    switches, through ssa_verify_batch_msm against the oracle's src/batch.rs restatement"""
+    rng = np.random.default_rng(3500 + n)
+    sigs, pks, msgs = honest(engine, rng, n)
+    co = coeffs32(rng, n)
+    assert engine.verify_batch_msm(sigs, pks, msgs, coeffs=co) == 0
+    assert engine.verify_batch_msm(sigs, pks, msgs) == 0
+    bad = sigs.copy()
+    bad[n // 3, 60] ^= 1
+    assert engine.verify_batch_msm(bad, pks, msgs, coeffs=co) == 2
+    und = sigs.copy()
+    und[n - 1, 48] = 0xff
+    assert engine.verify_batch_msm(und, pks, msgs, coeffs=co) == 3
+    dup = sigs.copy()
+    dupk = pks.copy()
+    dupm = msgs.copy()
+    dup[1], dupk[1], dupm[1] = sigs[0], pks[0], msgs[0]                       # equal points meet in one bucket / table
+    assert engine.verify_batch_msm(dup, dupk, dupm, coeffs=co) == 0
+    if n <= 128:
+        assert oracle.verify_batch_msm(sigs, pks, msgs, co) == 0 and oracle.verify_batch_msm(bad, pks, msgs, co) == 2
+        assert oracle.verify_batch_msm(und, pks, msgs, co) == 3 and oracle.verify_batch_msm(dup, dupk, dupm, co) == 0
+
+
+# ---------------------------------------------------------------- Rescue S-boxes: the flagged-lane fallback on hardware
+def test_sbox_blocks_flag_and_recompute_the_rare_borrow(engine):
+    """The generated S-box blocks (tools/gen_fp_chain_asm.py) leave one event of their reduction to the caller: a
+    borrow with probability ~2^-32 per squaring.  x = k 2^48 forces it in the first squaring (x^2 = k^2 2^96: lo = 0,
+    hi.lo = 0).  On the GPU: the blocks must flag exactly those lanes and hand their inputs back, the wrappers must
+    return the right values for EVERY lane (flagged ones through the compiled chain), neighbours unaffected."""
+    P = 2**64 - 2**32 + 1
+    e_inv = 10540996611094048183
+    rng = np.random.default_rng(3600)
+    n = 256
+    a = rng.integers(0, 2**64, size=(n, 2), dtype=np.uint64)
+    forced = np.zeros(n, bool)
+    for i in range(0, n, 7):                     # sprinkled over the waves, either chain
+        a[i, i % 2] = np.uint64((int(rng.integers(1, 2**16)) << 48))
+        forced[i] = True
+    a[3] = (0, 1)
+    a[4] = (P - 1, P)
+    a[5] = (2**64 - 1, 2**32)
+    out = engine.debug_arith(18, a, None, 6)
+    for i in range(n):
+        x, y = int(a[i, 0]), int(a[i, 1])
+        assert [int(v) for v in out[i, :4]] == [pow(x, 7, P), pow(y, 7, P), pow(x, e_inv, P), pow(y, e_inv, P)], i
+        if forced[i]:
+            assert out[i, 4] == 1 and out[i, 5] == 1, (i, out[i, 4:])        # flagged, inputs handed back (0xbad otherwise)
+    assert not (out[:, 4:] == 0xbad).any()
+    plain = ~forced
+    plain[3:6] = False
+    assert (out[plain, 4:] == 0).all()           # a random value does not get there (2^-32 per squaring)
+
+
+def test_hash_of_inputs_that_force_the_sbox_fallback(engine, oracle):
+    """whole-hash check of the same event: felts k 2^48 enter the first forward S-box layer directly"""
+    rng = np.random.default_rng(3601)
+    felts = rng.integers(0, 2**63, size=(512, 25), dtype=np.uint64)
+    felts[::3, :8] = (rng.integers(1, 2**16, size=(felts[::3].shape[0], 8)).astype(np.uint64) << np.uint64(48))
+    got = engine.rescue_hash_many(felts)
+    want = oracle.hash_field_many(felts)
+    assert (got == want).all()

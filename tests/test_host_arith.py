@@ -21,13 +21,19 @@ u64p = C.POINTER(C.c_uint64)
 
 @pytest.fixture(scope="module")
 def ha():
+    if os.environ.get("HOST_ARITH_LIB"):      # tests/test_sanitizers.py: the ASan + UBSan build of the same source
+        lib = C.CDLL(os.environ["HOST_ARITH_LIB"])
+        return _bind(lib)
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
     csrc = os.path.join(os.path.dirname(HERE), "schnorr-sig_amd", "csrc")
     deps = [SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-x", "hip", "-O2", "-shared", "-fPIC", SRC, "-o", LIB])
-    lib = C.CDLL(LIB)
+    return _bind(C.CDLL(LIB))
+
+
+def _bind(lib):
     for f in ("ha_fp_mul", "ha_fp_add", "ha_fp_sub"):
         getattr(lib, f).restype = C.c_uint64
         getattr(lib, f).argtypes = [C.c_uint64, C.c_uint64]

@@ -313,7 +313,11 @@ def emit(name, terms, inputs, doc, extras=()):
     return out, len(lines), nm
 
 
-def main():
+OUT_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc", "fp6_asm.inc")
+
+
+def generate():
+    """the text of fp6_asm.inc (the freshness test compares it with the committed file without writing anything)"""
     hdr = ["// generated by tools/gen_f6_asm.py -- do not edit (see that file for the design notes)"]
     m, nl, nm = emit("f6_mul_core_asm", mul_terms(), [("a", "a"), ("b", "b"), ("b7", "s")],
                      "r = a * b in Fp[u]/(u^6 - 7); b7[j] = 7 b[j] (j = 1..5)")
@@ -338,11 +342,14 @@ def main():
         blk, nl, nmad = emit(nm, terms, ins, doc, ex)
         print("%s: %d instructions, %d mads" % (nm, nl, nmad))
         fused += [""] + blk
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc",
-                        "fp6_asm.inc")
-    with open(path, "w") as fh:
-        fh.write("\n".join(hdr + m + [""] + s + fused) + "\n")
-    print("wrote", path)
+    return "\n".join(hdr + m + [""] + s + fused) + "\n"
+
+
+def main():
+    text = generate()
+    with open(OUT_PATH, "w") as fh:
+        fh.write(text)
+    print("wrote", OUT_PATH)
 
 
 if __name__ == "__main__":

@@ -17,6 +17,17 @@ issues only every ~6 cycles -- slower in spite of fewer instructions.
 One squaring, a = a0 + 2^32 a1 (three multiplies, fp.hpp fp_sqr3):
     t0 = a0^2;  u = a0 a1 + (t0 >> 33);  hi = a1^2 + (u >> 31);  lo = (t0 mod 2^33) | (u mod 2^31) << 33
 reduction (fp_reduce128): r = lo - hi.hi [borrow: + p] + EPS * hi.lo [carry: + EPS]
+
+Round 3 -- the reduction tail in THREE instructions, 11 VALU per squaring instead of 14 (and two scalar ones as before).
+After X = (EPS * h0 + lo) mod 2^64 with carry c (one multiply-add) the value wanted is X + c * EPS - h1 (h1 = hi.hi < 2^32):
+  * c = 1: X <= 2^64 - 2^33, so X + EPS - h1 = X + ~h1 can neither carry nor borrow;
+  * c = 0: X - h1 borrows only when X < h1 < 2^32 -- probability ~2^-32 for the values of a hash.
+Both cases are ONE 64-bit subtraction with c as the borrow-in of the low word (X.lo - h1 - c) and the high word
+X.hi - (c ? 0xffffffff : 0) - borrow, i.e. v_subb, v_cndmask, v_subb.  The rare borrow of the c = 0 case (the value would
+need + p) is NOT repaired in the chain: the borrow-out of the last v_subb, masked by "not c", is OR-ed into a sticky SGPR
+pair per chain (two scalar instructions per squaring, where the old tail spent two on combining its masks), the block
+reports the lanes that hit it, and the C++ wrapper recomputes those lanes' S-boxes with the compiled exact code
+(rescue.hpp).  Wrong intermediate values in a flagged lane are harmless: nothing of it is kept.
 """
 import os
 
@@ -39,6 +50,8 @@ def regs(c):
 
 
 DUMMY = "s[24:25]"     # carry-outs nobody reads
+STICKY = 40            # s[40:41] / s[42:43]: lanes of chain 0 / 1 whose reduction met the rare borrow (see the docstring)
+SGPRS = list(range(20, 32)) + list(range(36, 44))
 
 
 def vp(r):
@@ -64,25 +77,20 @@ def square(c):
         ("v_lshrrev_b64 %s, 31, %s" % (vp(H), vp(U)), [], []),
         ("v_lshl_or_b32 v%d, v%d, 1, v%d" % (T + 1, U, T + 1), [], []),           # lo = v[T:T+1]
         ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, X + 1, vp(H)), [], []),   # hi
-        # reduction: V = lo - top + EPS * h0 = X + (c - b) 2^64 with b the borrow of the subtraction and c the carry of
-        # the addition (both mod 2^64), and 2^64 = EPS: ONE correction by k EPS, k = c - b in {-1, 0, 1}
-        #   k = +1: X <= 2^64 - 2^33, no second carry;  k = -1: X >= p, no second borrow;  b and c both: nothing
-        # lo + EPS * hi.lo in ONE multiply-add (the 64-bit addend is lo, the carry-out c goes to s2), then - hi.hi
+        # reduction (see the module docstring): X = EPS * h0 + lo (carry c -> s2), then X + c EPS - h1 as one 64-bit
+        # subtraction with borrow-in c; a final borrow while c = 0 is the rare "+ p" case: sticky, repaired by the caller
         ("v_mad_u64_u32 %s, %s, v%d, -1, %s" % (vp(X), sp(S2), H, vp(T)), [], [S2]),
-        ("v_sub_co_u32 v%d, %s, v%d, v%d" % (X, s, X, H + 1), [], [S]),
-        ("v_subbrev_co_u32 v%d, %s, 0, v%d, %s" % (X + 1, s, X + 1, s), [S], [S]),                  # b -> s
-        ("s_andn2_b64 %s, %s, %s" % (sp(S3), s, sp(S2)), [], []),                                     # k = -1: b and not c
-        ("s_andn2_b64 %s, %s, %s" % (sp(S2), sp(S2), s), [], []),                                     # k = +1: c and not b
-        ("v_cndmask_b32 v%d, 0, 1, %s" % (E, sp(S3)), [], []),                                        # -EPS = (1, -1)
-        ("v_cndmask_b32 v%d, 0, -1, %s" % (E + 1, sp(S3)), [], []),
-        ("v_cndmask_b32 v%d, v%d, -1, %s" % (E, E, sp(S2)), [], []),                                  # +EPS = (-1, 0)
-        ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(X), vp(E), vp(X)), [], []),
+        ("v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (X, s, X, H + 1, sp(S2)), [], [S]),                  # X.lo - h1 - c
+        ("v_cndmask_b32 v%d, 0, -1, %s" % (E, sp(S2)), [], []),                                       # c ? 0xffffffff : 0
+        ("v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (X + 1, sp(S3), X + 1, E, s), [], [S3]),             # X.hi + c - borrow
+        ("s_andn2_b64 %s, %s, %s" % (sp(S3), sp(S3), sp(S2)), [], []),                                # borrow and not c
+        ("s_or_b64 %s, %s, %s" % (sp(STICKY + 2 * c), sp(STICKY + 2 * c), sp(S3)), [], []),
     ]
 
 
 def reduce_tail(c):
-    """lo = v[T:T+1], hi = v[H:H+1] -> X (the last ten instructions of square())"""
-    return square(c)[7:]      # from the subtraction of hi.hi on
+    """lo = v[T:T+1], hi = v[H:H+1] -> X (the last six instructions of square())"""
+    return square(c)[7:]      # from the multiply-add by EPS on
 
 
 def multiply(c, saved):
@@ -123,12 +131,21 @@ INV_SBOX = [("cp", "V0", "X"), ("sq", 1), ("cp", "V1", "X"), ("sq", 1), ("cp", "
 SBOX = [("cp", "V0", "X"), ("sq", 1), ("cp", "V1", "X"), ("sq", 1), ("mul", "V1"), ("mul", "V0")]   # x^7 = x^4 x^2 x
 
 
+# the sticky "rare borrow" masks of the two chains: cleared on entry; on exit their OR becomes the per-lane flag
+STICKY_INIT = ["s_mov_b64 %s, 0" % sp(STICKY), "s_mov_b64 %s, 0" % sp(STICKY + 2)]
+STICKY_OUT = ["s_or_b64 %s, %s, %s" % (sp(STICKY), sp(STICKY), sp(STICKY + 2)), "s_nop 2",
+              "v_cndmask_b32 %%[fl], 0, 1, %s" % sp(STICKY)]
+
+
 def emit_program(name, prog, doc):
     g0, g1 = regs(0), regs(1)
-    lines = ["// %s" % doc, "SSA_DEV void %s(u64 &x, u64 &y) {" % name,
-             "    u32 x0 = lo32(x), x1 = hi32(x), y0 = lo32(y), y1 = hi32(y);", "    asm volatile("]
-    body = ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
-            "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
+    lines = ["// %s" % doc,
+             "// returns non-zero in the lanes where a reduction met its rare borrow: x and y then come back UNCHANGED and the",
+             "// caller recomputes them with the compiled exact code",
+             "SSA_DEV u32 %s(u64 &x, u64 &y) {" % name,
+             "    u32 x0 = lo32(x), x1 = hi32(x), y0 = lo32(y), y1 = hi32(y), fl;", "    asm volatile("]
+    body = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
+                          "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
     for g in (g0, g1):
         body += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1)]
     n_loop = 0
@@ -155,15 +172,21 @@ def emit_program(name, prog, doc):
             body += seg
             counts["valu"] += sum(1 for ln in seg if ln.startswith("v_"))
             counts["nop"] += sum(1 for ln in seg if ln.startswith("s_nop"))
-    body += ["v_mov_b32 %%[x0], v%d" % g0["X"], "v_mov_b32 %%[x1], v%d" % (g0["X"] + 1),
-             "v_mov_b32 %%[y0], v%d" % g1["X"], "v_mov_b32 %%[y1], v%d" % (g1["X"] + 1)]
+    # results out -- or, in a flagged lane, the INPUTS back (V0 still holds them: both programs save x there first
+    # and never overwrite it), so that the caller recomputes from x, y themselves and keeps no copy alive across the block
+    assert prog[0] == ("cp", "V0", "X") and not any(op[0] == "cp" and op[1] == "V0" for op in prog[1:])
+    body += STICKY_OUT[:2] + \
+        ["v_cndmask_b32 %%[x0], v%d, v%d, %s" % (g0["X"], g0["V0"], sp(STICKY)),
+         "v_cndmask_b32 %%[x1], v%d, v%d, %s" % (g0["X"] + 1, g0["V0"] + 1, sp(STICKY)),
+         "v_cndmask_b32 %%[y0], v%d, v%d, %s" % (g1["X"], g1["V0"], sp(STICKY)),
+         "v_cndmask_b32 %%[y1], v%d, v%d, %s" % (g1["X"] + 1, g1["V0"] + 1, sp(STICKY))] + STICKY_OUT[2:]
     for i, ln in enumerate(body):
         lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(body) else ""))
-    lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1)')
+    lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1), [fl] "=&v"(fl)')
     lines.append("        :")
-    clob = ['"v%d"' % r for r in range(BASE, BASE + 4 * N_PAIRS)] + ['"s%d"' % r for r in list(range(20, 32)) + list(range(36, 40))] + ['"scc"', '"vcc"']
+    clob = ['"v%d"' % r for r in range(BASE, BASE + 4 * N_PAIRS)] + ['"s%d"' % r for r in SGPRS] + ['"scc"', '"vcc"']
     lines.append("        : " + ", ".join(clob) + ");")
-    lines += ["    x = mk64(x0, x1);", "    y = mk64(y0, y1);", "}"]
+    lines += ["    x = mk64(x0, x1);", "    y = mk64(y0, y1);", "    return fl;", "}"]
     print("%s: %d VALU instructions + %d s_nop for the two values" % (name, counts["valu"], counts["nop"]))
     return lines
 
@@ -185,7 +208,8 @@ def _regs_of(text):
         if m:
             return [("s", int(m.group(1)))]
         return []
-    n_dst = 2 if mnem in ("v_mad_u64_u32", "v_sub_co_u32", "v_subbrev_co_u32", "v_add_co_u32", "v_addc_co_u32") else 1
+    n_dst = 2 if mnem in ("v_mad_u64_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subbrev_co_u32", "v_add_co_u32",
+                          "v_addc_co_u32") else 1
     wr = [r for o in ops[:n_dst] for r in expand(o)]
     rd = [r for o in ops[n_dst:] for r in expand(o)]
     return rd, wr
@@ -193,8 +217,8 @@ def _regs_of(text):
 
 def schedule(chains):
     """list scheduling of the chains' instructions together: dependencies from the registers (RAW, WAW, WAR), an
-    SGPR pair written at position i is readable at i + 3 at the earliest (two wait states), longest remaining path
-    first; s_nop only where nothing else is ready"""
+    SGPR pair written by a VALU instruction at position i is readable by a VALU instruction at i + 3 at the earliest
+    (two wait states), longest remaining path first; s_nop only where nothing else is ready"""
     ins = [t for ch in chains for (t, _, _) in ch]
     info = [_regs_of(t) for t in ins]
     n = len(ins)
@@ -212,31 +236,54 @@ def schedule(chains):
     for j in range(n - 1, -1, -1):
         for i in preds[j]:
             height[i] = max(height[i], height[j] + 1)
-    placed_at = {}
-    out = []
-    last_sgpr_write = {}
-    while len(placed_at) < n:
-        best = None
-        for j in range(n):
-            if j in placed_at or any(i not in placed_at for i in preds[j]):
+
+    def place(prio):
+        placed_at = {}
+        out = []
+        last_sgpr_write = {}
+        while len(placed_at) < n:
+            best = None
+            for j in range(n):
+                if j in placed_at or any(i not in placed_at for i in preds[j]):
+                    continue
+                rd, wr = info[j]
+                # the wait states are a VALU-write -> VALU-read matter (gap 3); the scalar unit's reads of a pair a VALU
+                # instruction wrote are interlocked -- one other instruction is put in between anyway (gap 2)
+                gap = 3 if ins[j].startswith("v_") else 2
+                if any(r[0] == "s" and r[1] != 24 and len(out) - last_sgpr_write.get(r, -10) < gap for r in rd):
+                    continue
+                if best is None or prio[j] > prio[best]:
+                    best = j
+            if best is None:
+                out.append("s_nop 0")
                 continue
-            rd, wr = info[j]
-            if any(r[0] == "s" and r[1] != 24 and len(out) - last_sgpr_write.get(r, -10) < 3 for r in rd):
-                continue
-            if best is None or height[j] > height[best]:
-                best = j
-        if best is None:
-            out.append("s_nop 0")
-            continue
-        out.append(ins[best])
-        placed_at[best] = len(out) - 1
-        for r in info[best][1]:
-            if r[0] == "s":
-                last_sgpr_write[r] = len(out) - 1
-    return out
+            out.append(ins[best])
+            placed_at[best] = len(out) - 1
+            for r in info[best][1]:
+                if r[0] == "s" and ins[best].startswith("v_"):
+                    last_sgpr_write[r] = len(out) - 1
+        return out
+
+    # longest remaining path first; the greedy choice is not always the one without padding, so a few hundred
+    # deterministic perturbations of the priorities are tried as well and the schedule with the fewest s_nop kept
+    import random
+    rnd = random.Random(len(ins) * 7919 + sum(len(t) for t in ins))
+    best_out = place([float(h) for h in height])
+    for _ in range(300):
+        if not any(ln.startswith("s_nop") for ln in best_out):
+            break
+        cand = place([h + rnd.random() * 2.5 for h in height])
+        if sum(ln.startswith("s_nop") for ln in cand) < sum(ln.startswith("s_nop") for ln in best_out):
+            best_out = cand
+    return best_out
 
 
-def main():
+OUT_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc",
+                        "fp_chain_asm.inc")
+
+
+def generate():
+    """the text of fp_chain_asm.inc (the freshness test compares it with the committed file without writing anything)"""
     body = schedule([square(0), square(1)])
     n_valu = sum(1 for ln in body if ln.startswith("v_"))
     n_nop = sum(1 for ln in body if ln.startswith("s_nop"))
@@ -245,12 +292,12 @@ def main():
     lines.append("// generated by tools/gen_fp_chain_asm.py -- do not edit (see that file for the design notes)")
     lines.append("// x <- x^(2^n), y <- y^(2^n) (mod p, loose in / loose out), n >= 1: %d VALU instructions and %d s_nop per"
                  % (n_valu, n_nop))
-    lines.append("// pair of squarings.")
-    lines.append("SSA_DEV void fp_sqr2_n_asm(u64 &x, u64 &y, int n) {")
-    lines.append("    u32 x0 = lo32(x), x1 = hi32(x), y0 = lo32(y), y1 = hi32(y);")
+    lines.append("// pair of squarings.  Returns non-zero in the lanes where a reduction met its rare borrow (results invalid there).")
+    lines.append("SSA_DEV u32 fp_sqr2_n_asm(u64 &x, u64 &y, int n) {")
+    lines.append("    u32 x0 = lo32(x), x1 = hi32(x), y0 = lo32(y), y1 = hi32(y), fl;")
     lines.append("    asm volatile(")
-    pre = ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
-           "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
+    pre = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
+                         "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
     for g in (g0, g1):
         pre += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1)]
     pre += ["s_mov_b32 s26, %[n]"]
@@ -262,25 +309,30 @@ def main():
     for ln in ["s_sub_u32 s26, s26, 1", "s_cmp_lg_u32 s26, 0", "s_cbranch_scc1 L_fp_sqr2_%="]:
         lines.append('        "%s\\n\\t"' % ln)
     post = ["v_mov_b32 %%[x0], v%d" % g0["X"], "v_mov_b32 %%[x1], v%d" % (g0["X"] + 1),
-            "v_mov_b32 %%[y0], v%d" % g1["X"], "v_mov_b32 %%[y1], v%d" % (g1["X"] + 1)]
+            "v_mov_b32 %%[y0], v%d" % g1["X"], "v_mov_b32 %%[y1], v%d" % (g1["X"] + 1)] + STICKY_OUT
     for i, ln in enumerate(post):
         lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(post) else ""))
-    lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1)')
+    lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1), [fl] "=&v"(fl)')
     lines.append('        : [n] "s"(n)')
     used = sorted(set(range(BASE, BASE + 4 * 9)))
     progs = emit_program("inv_sbox2_asm", INV_SBOX, "x <- x^(1/7), y <- y^(1/7): the whole 63-squaring / 9-product chain of "
                          "both values in one block") + [""] + \
         emit_program("sbox2_asm", SBOX, "x <- x^7, y <- y^7")
-    clob = ['"v%d"' % r for r in used] + ['"s%d"' % r for r in list(range(20, 32)) + list(range(36, 40))] + ['"scc"', '"vcc"']
+    clob = ['"v%d"' % r for r in used] + ['"s%d"' % r for r in SGPRS] + ['"scc"', '"vcc"']
     lines.append("        : " + ", ".join(clob) + ");")
     lines.append("    x = mk64(x0, x1);")
     lines.append("    y = mk64(y0, y1);")
+    lines.append("    return fl;")
     lines.append("}")
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc",
-                        "fp_chain_asm.inc")
-    with open(path, "w") as fh:
-        fh.write("\n".join(lines + [""] + progs) + "\n")
-    print("wrote %s: %d VALU + %d s_nop per pair of squarings" % (path, n_valu, n_nop))
+    print("%d VALU + %d s_nop per pair of squarings" % (n_valu, n_nop))
+    return "\n".join(lines + [""] + progs) + "\n"
+
+
+def main():
+    text = generate()
+    with open(OUT_PATH, "w") as fh:
+        fh.write(text)
+    print("wrote", OUT_PATH)
 
 
 if __name__ == "__main__":

@@ -494,13 +494,21 @@ def emit_window():
     return out
 
 
-def main():
+OUT_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc", "jac_asm.inc")
+
+
+def generate():
+    """the text of jac_asm.inc (the freshness test compares it with the committed file without writing anything)"""
     out = ["// generated by tools/gen_jac_asm.py -- do not edit (see that file for the design notes)"] + emit_dbl() + [""] + emit_madd() \
         + [""] + emit_window()
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc", "jac_asm.inc")
-    with open(path, "w") as fh:
-        fh.write("\n".join(out) + "\n")
-    print("wrote", path)
+    return "\n".join(out) + "\n"
+
+
+def main():
+    text = generate()
+    with open(OUT_PATH, "w") as fh:
+        fh.write(text)
+    print("wrote", OUT_PATH)
 
 
 if __name__ == "__main__":

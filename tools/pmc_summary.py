@@ -20,6 +20,19 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "schnorr-sig_amd", "csrc", "libschnorr_sig_amd.so")
+sys.path.insert(0, ROOT)
+
+
+def _work_executed():
+    """64x64 products per signature the kernels execute (bench.py's formulas)"""
+    try:
+        import bench
+        return {"ssa_k_verify": bench.W_VERIFY_EXECUTED, "ssa_k_hash": bench.W_HASH}
+    except Exception:
+        return {}
+
+
+WORK_EXECUTED = _work_executed()
 
 
 def load(d):
@@ -109,6 +122,17 @@ def main():
                 cycles = e["GRBM_GUI_ACTIVE"] / 8.0 * (s["ms"] / w["ms"])
                 e["clock_GHz"] = e["GRBM_GUI_ACTIVE"] / 8.0 / (w["ms"] * 1e6)
                 e["cycles_per_valu_instruction_per_simd"] = cycles * 1024 / s["SQ_INSTS_VALU"]
+                # the names bench.py prints (roofline.pmc): VALU utilisation as issue cycles per instruction per SIMD
+                # (4.0 = one wave64 instruction every pass of the 16-lane SIMD: back-to-back issue) and the share of
+                # wave cycles in which the wave has a VALU instruction in flight
+                e["valu_cycles_per_instruction"] = e["cycles_per_valu_instruction_per_simd"]
+            if "SQ_ACTIVE_INST_VALU_frac" in e:
+                e["valu_active_frac"] = e["SQ_ACTIVE_INST_VALU_frac"]
+            wp = WORK_EXECUTED.get(kern)
+            if wp:
+                # VALU wave-instructions per lane per 64x64 product the kernel executes (4 = multiplies only)
+                e["valu_instructions_per_lane"] = s["SQ_INSTS_VALU"] * 64.0 / args.batch
+                e["valu_instructions_per_product"] = e["valu_instructions_per_lane"] / wp
             for c in ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64"):
                 if c in s:
                     e[c + "_share"] = s[c] / s["SQ_INSTS_VALU"]
