@@ -364,33 +364,48 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
     st_f6(tab + PTAB_NY, f6_neg(p.y));
 }
 
+#include "qnaf.inc"
+
 // [k]P, k < 2^255, from the lane's affine table with signed 4-bit windows (offset recoding):
 // the top window only selects its table entry, then 63 x (4 doublings + 1 mixed addition) with
 // every lane in lock-step.
-SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k) {
+// order_q: [q]P for the subgroup check (is_torsion_free, src/signature.rs:182) -- the scalar is a constant, so its
+// schedule is chosen offline: the width-4 NAF of q (qnaf.inc, tools/gen_qnaf.py), 52 additions and 255 doublings with a
+// variable number of doublings per window instead of 59 + 252 (k is ignored).  Same loop, same window statement: the
+// ladder body exists once in the code.
+SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q = false) {
     const sc256 kr = sc_recode_offset(k);
     jac acc = jac_identity();
-    const u32 top = sc_nibble(kr, 63u);   // in [0, 8]
+    const u32 top = order_q ? (u32)QNAF_DIGIT[0] : sc_nibble(kr, 63u);   // in [0, 8]
     if (top != 0) {
         const aff p = ld_aff(tab + (top - 1) * PTAB_ENTRY_U64);
         if (!(f6_is_zero(p.x) && f6_is_zero(p.y))) acc = jac_from_aff(p);
     }
+    const int steps = order_q ? QNAF_LEN - 1 : 63;
 #pragma unroll 1
-    for (int w = 62; w >= 0; w--) {
-        const int digit = (int)sc_nibble(kr, (u32)w) - 8;
+    for (int it = 0; it < steps; it++) {
+        int digit;
+        u32 gap;
+        if (order_q) {
+            digit = (int)QNAF_DIGIT[it + 1];
+            gap = (u32)QNAF_GAP[it + 1];
+        } else {
+            digit = (int)sc_nibble(kr, (u32)(62 - it)) - 8;
+            gap = 4u;
+        }
         const int mag = digit < 0 ? -digit : digit;
 #ifdef SSA_JAC_ASM
-        // one asm statement per window: 4 doublings + the addition on the lanes with a non-zero digit; -y comes from
+        // one asm statement per window: `gap` doublings + the addition on the lanes with a non-zero digit; -y comes from
         // the table, so the loop body outside the statement is the digit, one address and six loads
         const u64 *row = tab + (size_t)((mag ? mag : 1) - 1) * PTAB_ENTRY_U64;
         aff q;
         q.x = ld_f6(row);
         q.y = ld_f6(row + (digit < 0 ? PTAB_NY : 6));
-        if (!jac_window_asm(acc.X.c, acc.Y.c, acc.Z.c, q.x.c, q.y.c, (u32)mag, 4u)) {
+        if (!jac_window_asm(acc.X.c, acc.Y.c, acc.Z.c, q.x.c, q.y.c, (u32)mag, gap)) {
             if (digit != 0) acc = jac_madd(acc, q);      // exceptional inputs: the exact compiled addition
         }
 #else
-        acc = jac_dbl_n(acc, 4u);
+        acc = jac_dbl_n(acc, gap);
         if (digit != 0) {
             aff q = ld_aff(tab + (mag - 1) * PTAB_ENTRY_U64);
             q.y = f6_select(digit < 0, q.y, f6_neg(q.y));
@@ -478,12 +493,7 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
                     status = ST_MALFORMED;
                     break;
                 }
-                sc256 k = h;
-                if (pass == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) k.w[j] = SC_Q(j);
-                }
-                r = mul_ptab(tab, k);
+                r = mul_ptab(tab, h, pass == 0);        // pass 0: the offline schedule of the constant q
                 if (pass == 0 && !jac_is_identity(r)) {
                     status = ST_INVALID_PK;
                     break;
@@ -544,7 +554,7 @@ ssa_k_keyset_build(const u8 *__restrict__ pks, const u8 *__restrict__ pk_inf, si
         sc256 q;
 #pragma unroll
         for (int j = 0; j < 4; j++) q.w[j] = SC_Q(j);
-        st = jac_is_identity(mul_ptab(tab, q)) ? ST_OK : ST_INVALID_PK;
+        st = jac_is_identity(mul_ptab(tab, q, true)) ? ST_OK : ST_INVALID_PK;
     }
     key_status[i] = (u8)st;
 }

@@ -113,6 +113,7 @@ class Lane:
                 kd, ka, kb = self._key(a[0]), self._key(a[1]), self._key(a[2])
                 self.s[kd] = self.s.get(ka, 0) & (1 - self.s.get(kb, 0))
                 self.written_at[kd] = -100  # written by the scalar unit: no VALU-write wait states
+                scc = self.s[kd] != 0       # SCC = (result != 0): one lane's view of the wave-wide mask
             elif op == "s_sub_u32":
                 k = int(a[0][1:])
                 self.salu32[k] = (self.salu32[k] - self.rv(a[2])) & M32
@@ -141,6 +142,7 @@ class Lane:
                 kd, ka, kb = self._key(a[0]), self._key(a[1]), self._key(a[2])
                 self.s[kd] = self.s.get(ka, 0) | self.s.get(kb, 0)
                 self.written_at[kd] = -100
+                scc = self.s[kd] != 0
             elif op == "s_branch":
                 pc = labels[a[0]]
             elif op == "s_and_b64":
@@ -148,6 +150,7 @@ class Lane:
                 kd = self._key(a[0])
                 self.s[kd] = bit(a[1]) & bit(a[2])
                 self.written_at[kd] = -100
+                scc = self.s[kd] != 0
             elif op in ("v_cmp_le_u32", "v_cmp_eq_u32", "v_cmp_ne_u32"):
                 x, y = self.rv(a[1]), self.rv(a[2])
                 self.wc(a[0], int({"le": x <= y, "eq": x == y, "ne": x != y}[op[6:8]]))

@@ -98,6 +98,58 @@ def test_reduction_tail_is_exact_or_flagged():
     assert n_flag >= 20 and n_carry > 500
 
 
+def test_fp6_reduction_group_is_exact_including_its_cold_path():
+    """gen_f6_asm.reduce3 -- three accumulators reduced round-robin, the rare negative result repaired behind ONE branch
+    per group -- on raw accumulator contents: random columns and counters, and contents built to land on every
+    boundary (X + c EPS < top with and without the carry, th - c wrapping, all three chains at once, one chain only)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_f6_asm as g6
+    accs = [g6.Acc(j) for j in range(3)]
+    outs = [("v%d" % (200 + 2 * j), "v%d" % (201 + 2 * j)) for j in range(3)]
+    hot, cold = g6.reduce3(accs, outs, "t")
+    lines = hot + ["s_branch L_end_%="] + cold + ["L_end_%=:"]
+    assert sum(ln.startswith("v_") for ln in hot) == 33          # 11 per coefficient
+    rnd = random.Random(99)
+    EPS = 2**32 - 1
+
+    def value(c0, c1, c2, k0, k1, k2):
+        return c0 + (c1 << 32) + ((c2 + k0) << 64) + (k1 << 96) + (k2 << 128)
+
+    crafted = [
+        (0, 0, 5 << 32, 0, 0, 0),                 # X = 0, no carry, top = 5: negative
+        (0, 0, 0, 0, 7, 0),                       # top from the counter k1
+        (P, 0, 0, 1, 0, 1),                       # carry, X = 0, X + EPS < top = 2^32: negative with c = 1
+        (P + 1, 0, 0, 1, 0, 1),                   # carry, X + EPS = top: exactly zero, not negative
+        (P, 0, 0, 1, 0, 0),                       # carry and th = 0: th - c wraps, must NOT be flagged
+        (2**64 - 1, 2**64 - 1, 2**64 - 1, 15, 15, 15),
+        (0, 0, 0, 0, 0, 0),
+        (1, 0, (2**32 - 1) << 32, 0, 15, 15),     # largest top against a tiny X
+        (0, 1 << 32, 0, 0, 0, 3),                 # sl = 1: X = EPS, top = 3 * 2^32
+    ]
+    n_cold = 0
+    for trial in range(400):
+        sets = []
+        for j in range(3):
+            if trial < 60:
+                sets.append(crafted[(trial + j * (trial // 9 + 1)) % len(crafted)] if (trial + j) % 4 else
+                            tuple([rnd.randrange(2**64) for _ in range(3)] + [rnd.randrange(16) for _ in range(3)]))
+            else:
+                c = [rnd.randrange(2**64) if rnd.random() < 0.8 else rnd.choice([0, 1, P, 2**64 - 1, 2**32]) for _ in range(3)]
+                sets.append(tuple(c + [rnd.randrange(16) for _ in range(3)]))
+        lane = ai.Lane({}, dummy_pairs=())
+        for a, (c0, c1, c2, k0, k1, k2) in zip(accs, sets):
+            for i, cv in enumerate((c0, c1, c2)):
+                lane.v[a.c[i][0]], lane.v[a.c[i][1]] = cv & M32, cv >> 32
+            for i, kv in enumerate((k0, k1, k2)):
+                lane.v[a.k[i]] = kv
+        lane.run(lines)
+        for j, st in enumerate(sets):
+            got = lane.v[200 + 2 * j] | (lane.v[201 + 2 * j] << 32)
+            assert got % P == value(*st) % P, (trial, j, [hex(x) for x in st])
+        n_cold += any(lane.s.get(14 + 2 * j, 0) for j in range(3))
+    assert n_cold >= 20
+
+
 def _f6_mulmod(u, v):
     t = [0] * 12
     for i, x in enumerate(u):
@@ -414,7 +466,7 @@ def test_doubling_asm_declares_its_registers_and_kernels_leave_room():
 
 
 def test_generated_files_are_up_to_date():
-    """fp_chain_asm.inc, jac_asm.inc and fp6_asm.inc are what their generators produce (no hand edits, no stale
+    """fp_chain_asm.inc, jac_asm.inc, fp6_asm.inc and qnaf.inc are what their generators produce (no hand edits, no stale
     generator).  The text is generated IN MEMORY and compared: a test must not write tracked sources (a rewrite bumps
     their mtimes, and a stale generator would overwrite the committed file before the assertion fires)."""
     import importlib.util
@@ -422,7 +474,8 @@ def test_generated_files_are_up_to_date():
     from contextlib import redirect_stdout
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
-    for tool, inc in (("gen_fp_chain_asm", "fp_chain_asm.inc"), ("gen_jac_asm", "jac_asm.inc"), ("gen_f6_asm", "fp6_asm.inc")):
+    for tool, inc in (("gen_fp_chain_asm", "fp_chain_asm.inc"), ("gen_jac_asm", "jac_asm.inc"), ("gen_f6_asm", "fp6_asm.inc"),
+                      ("gen_qnaf", "qnaf.inc")):
         path = os.path.join(root, "schnorr-sig_amd", "csrc", inc)
         mtime = os.path.getmtime(path)
         spec = importlib.util.spec_from_file_location(tool, os.path.join(root, "tools", tool + ".py"))
@@ -433,3 +486,20 @@ def test_generated_files_are_up_to_date():
         assert os.path.abspath(mod.OUT_PATH) == os.path.abspath(path)
         assert text == open(path).read(), "%s is not what tools/%s.py generates" % (inc, tool)
         assert os.path.getmtime(path) == mtime, "the freshness test wrote " + inc
+
+
+def test_order_q_schedule_is_q():
+    """qnaf.inc: the (gap, digit) schedule the subgroup check runs evaluates to the subgroup order (plain integers),
+    uses only table rows 1P..7P and never asks the window statement for zero doublings"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "schnorr-sig_amd", "csrc", "qnaf.inc")).read()
+    digits = [int(v) for v in re.search(r"QNAF_DIGIT\[QNAF_LEN\] = \{(.*?)\}", txt).group(1).split(",")]
+    gaps = [int(v) for v in re.search(r"QNAF_GAP\[QNAF_LEN\] = \{(.*?)\}", txt).group(1).split(",")]
+    n = int(re.search(r"QNAF_LEN = (\d+)", txt).group(1))
+    assert len(digits) == len(gaps) == n
+    acc = 0
+    for g, d in zip(gaps, digits):
+        acc = (acc << g) + d
+    assert acc == 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
+    assert gaps[0] == 0 and 1 <= digits[0] <= 8 and all(1 <= g <= 64 for g in gaps[1:])
+    assert all(d % 2 and abs(d) <= 7 for d in digits)

@@ -24,6 +24,8 @@ Reduction of one accumulator (value = c0 + 2^32 c1 + 2^64 (c2 + k0) + 2^96 k1 + 
   sl = c1h + c2l + k0 + cL      (its carries ca, cb weigh 2^96 = -1: folded into t0)
   t0 = c2h + k1 + ca + cb,  th = k2 + carries of t0
   r  = (c0l, m) - (t0, th) [borrow: - EPS] + EPS * sl [carry: + EPS]        -- as fp_reduce_parts
+(round 3: the tail is one multiply-add and three carry instructions, the rare negative result goes to a cold path
+behind one branch per group of three reductions: see REDUCE_STEPS)
 """
 import os
 
@@ -186,34 +188,51 @@ REDUCE_STEPS = [
     "v_addc_co_u32 {c2h}, {B}, 0, {c2h}, {B}",        # 5  t0 += cb
     "v_addc_co_u32 {k2}, {A}, 0, {k2}, {A}",          # 6  th = k2 + carry(4)
     "v_addc_co_u32 {k2}, {B}, 0, {k2}, {B}",          # 7  th += carry(5)
-    # r = (c0l, m) + EPS * sl - (t0, th): the multiply-add takes (c0l, m) as its 64-bit addend and delivers the carry
-    # c; the subtraction delivers the borrow b; they are worth +2^64 and -2^64 = +-EPS: ONE correction by k EPS,
-    # k = c - b.  k = +1: r <= 2^64 - 2^33, k = -1: r > 2^64 - 2^36 >= EPS -- neither wraps again; both: nothing.
-    # (Round 1: M = EPS * sl by two subtractions, borrow fix, 64-bit add, carry fix: 19 instructions, now 15.)
-    "v_mad_u64_u32 {c0p}, {A}, {c1h}, -1, {c0p}",     # 8  r = (c0l, m) + EPS * sl, carry c
-    "v_sub_co_u32 {c0l}, {B}, {c0l}, {c2h}",          # 9  r -= (t0, th), borrow b
-    "v_subb_co_u32 {c0h}, {B}, {c0h}, {k2}, {B}",     # 10
-    "s_andn2_b64 {T}, {A}, {B}",                      #    k = +1: c and not b      (scalar unit)
-    "s_andn2_b64 {B}, {B}, {A}",                      #    k = -1: b and not c
-    "v_cndmask_b32_e64 {k0}, 0, 1, {B}",              # 11 -EPS = (1, -1)
-    "v_cndmask_b32_e64 {k1}, 0, -1, {B}",             # 12
-    "v_cndmask_b32_e64 {k0}, {k0}, -1, {T}",          # 13 +EPS = (-1, 0)
-    "v_add_co_u32 {outl}, {A}, {c0l}, {k0}",          # 14 r += k EPS, straight into the output operand
-    "v_addc_co_u32 {outh}, {A}, {c0h}, {k1}, {A}",    # 15
+    # r = (c0l, m) + EPS * sl - (t0, th).  The multiply-add takes (c0l, m) as its 64-bit addend: X and the carry c (worth
+    # 2^64 = EPS).  Round 3: X + c EPS - top as ONE 64-bit subtraction with c as the borrow-in of the low word
+    # (EPS = 2^32 - 1: low word - 1, high word + 1):  low = X.lo - t0 - c,  high = X.hi - (th - c) - borrow.
+    #   c = 1: X <= 2^64 - 2^33, so X + EPS cannot carry;  the difference is negative only when X + c EPS < top < 2^36:
+    #   probability ~2^-28 per coefficient.  That rare lane is NOT repaired here: its mask (borrow of the high word,
+    #   unless th - c itself wrapped: th = 0, c = 1, where nothing can go wrong) goes to T, the three masks of a group
+    #   are OR-ed on the scalar unit and ONE branch per group leads to a cold path that subtracts EPS there
+    #   (value + 2^64 - EPS = value + p; value + 2^64 > 2^64 - 2^36 > EPS: no second borrow).
+    # 11 VALU instructions per coefficient (round 2: 15 -- borrow and carry settled by three selects and a 64-bit add;
+    # round 1: 19) and two scalar ones as before.
+    "v_mad_u64_u32 {c0p}, {A}, {c1h}, -1, {c0p}",     # 8  X = (c0l, m) + EPS * sl, carry c
+    "v_subb_co_u32 {outl}, {B}, {c0l}, {c2h}, {A}",   # 9  X.lo - t0 - c
+    "v_subbrev_co_u32 {k0}, {T}, 0, {k2}, {A}",       # 10 Z = th - c (wraps to 2^32 - 1 only for th = 0, c = 1: mask in T)
+    "v_subb_co_u32 {outh}, {B}, {c0h}, {k0}, {B}",    # 11 X.hi - Z - borrow
+    "s_andn2_b64 {T}, {B}, {T}",                      #    negative: final borrow and Z did not wrap   (scalar unit)
 ]
 
 
-def reduce3(accs, outs):
-    """outs[j] = (lo, hi) destination of chain j's result"""
+def reduce3(accs, outs, label):
+    """outs[j] = (lo, hi) destination of chain j's result; label: unique name stem of this group's cold path.
+    Returns (hot lines, cold lines): the hot lines end in a branch to the cold path (taken ~once in 10^8 groups) and the
+    label it returns to; the cold lines are to be placed out of the way by the caller."""
     lines = []
+    ms = []
+    for j, a in enumerate(accs):
+        ms.append({"c0p": a.pair(0), "c0l": a.lo(0), "c0h": a.hi(0), "c1l": a.lo(1), "c1h": a.hi(1), "c2l": a.lo(2), "c2h": a.hi(2),
+                   "k0": a.kk(0), "k1": a.kk(1), "k2": a.kk(2), "A": "s[%d:%d]" % (4 * j, 4 * j + 1),
+                   "B": "s[%d:%d]" % (4 * j + 2, 4 * j + 3), "T": "s[%d:%d]" % (14 + 2 * j, 15 + 2 * j),
+                   "outl": outs[j][0], "outh": outs[j][1]})
     for step in REDUCE_STEPS:
-        for j, a in enumerate(accs):
-            m = {"c0p": a.pair(0), "c0l": a.lo(0), "c0h": a.hi(0), "c1l": a.lo(1), "c1h": a.hi(1), "c2l": a.lo(2), "c2h": a.hi(2),
-                 "k0": a.kk(0), "k1": a.kk(1), "k2": a.kk(2), "A": "s[%d:%d]" % (4 * j, 4 * j + 1),
-                 "B": "s[%d:%d]" % (4 * j + 2, 4 * j + 3), "T": "s[%d:%d]" % (14 + 2 * j, 15 + 2 * j),
-                 "outl": outs[j][0], "outh": outs[j][1]}
+        for m in ms:
             lines.append(step.format(**m))
-    return lines
+    # any lane of any of the three chains negative?  (s_or sets SCC = result != 0; A of chain 0 is free by now)
+    u = ms[0]["A"]
+    lines += ["s_or_b64 %s, %s, %s" % (u, ms[0]["T"], ms[1]["T"]), "s_or_b64 %s, %s, %s" % (u, u, ms[2]["T"]),
+              "s_cbranch_scc1 L_%s_fix_%%=" % label, "L_%s_back_%%=:" % label]
+    cold = ["L_%s_fix_%%=:" % label]
+    for m in ms:        # - EPS = + (1, 2^32 - 1) in the flagged lanes; the counters are free
+        cold += ["v_cndmask_b32_e64 {k0}, 0, 1, {T}".format(**m), "v_cndmask_b32_e64 {k1}, 0, -1, {T}".format(**m)]
+    for m in ms:
+        cold += ["v_add_co_u32 {outl}, {A}, {outl}, {k0}".format(**m)]
+    for m in ms:
+        cold += ["v_addc_co_u32 {outh}, {A}, {outh}, {k1}, {A}".format(**m)]
+    cold += ["s_branch L_%s_back_%%=" % label]
+    return lines, cold
 
 
 def mul_terms():
@@ -261,6 +280,7 @@ def emit(name, terms, inputs, doc, extras=()):
     """extras: fused linear terms (sign, small constant, operand prefix); their operand arrays are appended to inputs"""
     accs = [Acc(j) for j in range(6)]
     lines = []
+    cold = []
     bias, bias_setup = extras_bias(extras)
     lines += bias_setup
     for g in range(2):
@@ -275,10 +295,13 @@ def emit(name, terms, inputs, doc, extras=()):
             outs = [("v%d" % RES[2 * j], "v%d" % RES[2 * j + 1]) for j in range(3)]
         else:
             outs = [("%%[r%dl]" % k, "%%[r%dh]" % k) for k in range(3, 6)]
-        lines += reduce3(accs[3 * g:3 * g + 3], outs)
+        hot, cld = reduce3(accs[3 * g:3 * g + 3], outs, "r%d" % g)
+        lines += hot
+        cold += cld
     for j in range(3):
         lines.append("v_mov_b32 %%[r%dl], v%d" % (j, RES[2 * j]))
         lines.append("v_mov_b32 %%[r%dh], v%d" % (j, RES[2 * j + 1]))
+    lines += ["s_branch L_end_%="] + cold + ["L_end_%=:"]
     used = set()
     for ln in lines:
         for tok in ln.replace(",", " ").split():

@@ -68,6 +68,7 @@ class Gen:
         self.main = []          # the loop body
         self.cold = []          # cold paths, after the loop
         self.nsite = 0
+        self.nred = 0           # groups of three reductions (one cold path each: gen_f6_asm.reduce3)
         a = self.al
         self.IN = [a.free.pop() for _ in range(n_pinned_in)][::-1]    # further pinned operands (highest free pairs)
         self.S = [a.fp6() for _ in range(n_slots)]    # Fp6 temporaries
@@ -168,7 +169,10 @@ class Gen:
                     lines += g6.mac(accs[k], x, y)
                 lines += g6.extra_terms(accs[k], k, extras)
             outs = [("v%d" % out[k], "v%d" % (out[k] + 1)) for k in range(3 * g, 3 * g + 3)]
-            lines += g6.reduce3(accs[3 * g:3 * g + 3], outs)
+            hot, cold = g6.reduce3(accs[3 * g:3 * g + 3], outs, "%sred%d" % (self.tag, self.nred))
+            self.nred += 1
+            lines += hot
+            self.cold += cold
         m = dict(regs)
         for _, _, prefix in extras:
             for k in range(6):
