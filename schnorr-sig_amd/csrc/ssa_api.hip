@@ -87,6 +87,7 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     ctx->default_params = is_default;
     if (const char *cm = std::getenv("SSA_COOP_MAX_N"))
         ctx->coop_max_n = ctx->coop_max_n_torsion = (size_t)std::strtoull(cm, nullptr, 10);
+    if (const char *sm = std::getenv("SSA_MSM_SMALL_MAX")) ctx->msm_small_max = (size_t)std::strtoull(sm, nullptr, 10);
     if (const char *vb = std::getenv("SSA_VERIFY_BLOCK")) {
         const int v = std::atoi(vb);
         if (v == 64 || v == 128 || v == 256) ctx->verify_block = (unsigned)v;

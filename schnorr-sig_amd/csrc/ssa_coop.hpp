@@ -15,7 +15,7 @@
 
 namespace ssa {
 
-constexpr int COOP_SLOTS = 72;
+constexpr int COOP_SLOTS = 105;     // 71 of the verification kernel + a second point and its 32-slot table (small-batch MSM form)
 
 // A slot holds an Fp6 value v (words 0..5) and 7*v (words 6..11): the product rounds read the wrapped
 // terms (u^6 = 7) of their second operand from the upper half, so nobody scales on the critical path.
@@ -407,7 +407,7 @@ COOP_FN void coop_jac_add(CoopLds &L, int P1, int P2, const int *t, u32 lane, in
 // inversions) and the slots both waves share (public key, signature x, the 8-entry table with rows X, Y, Z, C;
 // C holds W = Z^4 while the table is being built and the prefix products of the normalisation afterwards).
 namespace coop_slots {
-enum : int { WS_SLOTS = 18, PX = 2 * WS_SLOTS, PY, SX, TAB };
+enum : int { WS_SLOTS = 18, PX = 2 * WS_SLOTS, PY, SX, TAB, TAB2 = TAB + 32, RX = TAB2 + 32, RY = RX + 1 };
 }
 #define COOP_WORKING_SET(ws)                                                                               \
     const int AX = (ws) * coop_slots::WS_SLOTS, AY = AX + 1, AZ = AX + 2, AW = AX + 3, QX = AX + 4, QY = AX + 5,  \
@@ -482,13 +482,16 @@ COOP_FN sc256 coop_hash_message(CoopLds &L, const DevParams *__restrict__ prm, c
 }
 
 // affine multiples 1P..8P into the TAB slots (rows of X, Y, Z, C); identity multiples become (0, 0)
-COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane, int ws = 0) {
+// (tab, px, py: the table rows and the slots of the affine point they are built from -- TAB / PX / PY of the
+// verification kernel by default, TAB2 / RX / RY for the second point of the small-batch MSM form)
+COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane, int ws = 0, int tab = coop_slots::TAB,
+                              int px = coop_slots::PX, int py = coop_slots::PY) {
     using namespace coop_slots;
     COOP_WORKING_SET(ws);
     int t[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) t[k] = T0 + k;
-    auto row = [](int e, int f) { return TAB + 4 * e + f; };
+    auto row = [tab](int e, int f) { return tab + 4 * e + f; };
     if (p_inf) {
 #pragma unroll 1
         for (int e = 0; e < 8; e++) {
@@ -497,8 +500,8 @@ COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane, int ws = 0) {
         }
         return;
     }
-    coop_copy(L, row(0, 0), PX, lane, ws);
-    coop_copy(L, row(0, 1), PY, lane, ws);
+    coop_copy(L, row(0, 0), px, lane, ws);
+    coop_copy(L, row(0, 1), py, lane, ws);
     coop_set(L, row(0, 2), 1ull, lane, ws);
     coop_set(L, row(0, 3), 1ull, lane, ws);
     // (source row, operation): 2P = dbl 1P, 3P = 2P + P, 4P = dbl 2P, 5P = 4P + P, 6P = dbl 3P, 7P = 6P + P, 8P = dbl 4P
@@ -509,7 +512,7 @@ COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane, int ws = 0) {
         const int s = src[e - 1];
 #pragma unroll 1
         for (int f = 0; f < 4; f++) coop_copy(L, AX + f, row(s, f), lane, ws);
-        if (is_add[e - 1]) coop_jac_madd(L, AX, PX, PY, t, lane, ws);
+        if (is_add[e - 1]) coop_jac_madd(L, AX, px, py, t, lane, ws);
         else coop_jac_dbl(L, AX, t, lane, ws);
 #pragma unroll 1
         for (int f = 0; f < 4; f++) coop_copy(L, row(e, f), AX + f, lane, ws);
@@ -543,9 +546,11 @@ COOP_FN void coop_build_table(CoopLds &L, bool p_inf, u32 lane, int ws = 0) {
     }
 }
 
-// (AX, AY, AZ) <- [k] P from the table, k < 2^255
-COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane, int ws = 0) {
+// (AX, AY, AZ) <- [k] P from the table, k < 2^255.  Leading windows whose digit is zero are skipped while the
+// accumulator is still the identity (short scalars: the 128-bit coefficients of the MSM form).
+COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane, int ws = 0, int tab = coop_slots::TAB) {
     using namespace coop_slots;
+    const int TAB = tab;
     COOP_WORKING_SET(ws);
     int t[9];
 #pragma unroll
@@ -556,7 +561,9 @@ COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane, int ws = 0) {
     coop_set(L, AZ, 0ull, lane, ws);
     coop_set(L, AW, 0ull, lane, ws);
     const u32 top = sc_nibble(kr, 63u);
+    bool started = false;      // wave-uniform: some non-zero digit has been consumed
     if (top != 0) {
+        started = true;
         const int e = (int)top - 1;
         if (!(coop_is_zero(L, TAB + 4 * e, lane, ws) && coop_is_zero(L, TAB + 4 * e + 1, lane, ws))) {
             coop_copy(L, AX, TAB + 4 * e, lane, ws);
@@ -568,6 +575,8 @@ COOP_FN void coop_mul_table(CoopLds &L, const sc256 &k, u32 lane, int ws = 0) {
 #pragma unroll 1
     for (int w = 62; w >= 0; w--) {
         const int digit = (int)sc_nibble(kr, (u32)w) - 8;
+        if (digit == 0 && !started) continue;      // doublings of the identity
+        started = true;
         if (digit != 0) {   // the addend of this window (second operands only: no 7x halves needed)
             const int e = (digit < 0 ? -digit : digit) - 1;
             if (lane < 6) {

@@ -80,6 +80,8 @@ struct ssa_ctx {
     // batches up to these sizes take the cooperative (waves-per-signature) kernel: measured crossovers without /
     // with the subgroup check (tools/mode_crossover.py); SSA_COOP_MAX_N overrides both
     size_t coop_max_n = 7680, coop_max_n_torsion = 10496;   // lane kernels: 3.5 / 5.4 ms flat up to 2^15 (round 2, window asm)
+    size_t msm_small_max = 3072;  // MSM-form batches up to this size: one cooperative block per signature (measured
+                                  // crossover with the bucket method: tools/msm_small_crossover.py; SSA_MSM_SMALL_MAX)
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;
     std::vector<struct ssa_keyset *> keysets;   // live key sets of this context (orphaned, not leaked, by ssa_ctx_destroy)

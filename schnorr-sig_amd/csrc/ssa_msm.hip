@@ -393,6 +393,206 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
     }
 }
 
+// ---- small batches: Straus on cooperating waves ---------------------------------------------------
+// The bucket method pays ~20 launches of lone, latency-bound waves however small the batch is (2.5 ms at the
+// reference's own bench sizes, benches/schnorr.rs:78-96: 4..128 signatures).  Below MSM_SMALL_MAX signatures the
+// same equation is evaluated term by term instead: ONE two-wave block per signature computes
+//     T_i = [s_i] R_i - [s_i h_i] P_i      and      s_i e_i mod q
+// with the wave-cooperative arithmetic of ssa_coop.hpp (table of eight multiples + signed 4-bit windows for each
+// of the two points, the same code as the low-latency verification kernel), and writes them as one 24-word record
+// -- the very record a shard of a multi-process batch produces (include/schnorr_sig_amd.h), so the records are summed
+// by the same combination kernel.
+//   wave 0: stage, P on the curve, table of P      ||  wave 1: hash_message -> h, s h mod q, s e mod q
+//   wave 0: decompress R, table of R, [s] R        ||  wave 1: [s h] P from P's table, negate
+//   wave 0: T = [s]R + (-[s h]P), record
+struct MsmSmallShared {
+    u32 ok, r_ok, r_inf;
+    u64 s[4], b[4], se[4];
+};
+
+__global__ void __launch_bounds__(128)
+msm_k_small(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
+            const u8 *__restrict__ pk_inf, MsgView mv, const u8 *__restrict__ coeffs, u32 coeff_bytes, size_t n,
+            u64 *__restrict__ records) {
+    __shared__ CoopLds L;
+    __shared__ MsmSmallShared sh;
+    using namespace coop_slots;
+    const size_t i = blockIdx.x;
+    if (i >= n) return;
+    const u32 lane = threadIdx.x & 63u;
+    const int ws = (int)(threadIdx.x >> 6);
+    COOP_WORKING_SET(ws);
+    int t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = T0 + k;
+    const u8 *sig = sigs + 81 * i, *pk = pks + 96 * i;
+    const bool inf = pk_inf && pk_inf[i];
+    u64 *rec = records + 24 * i;
+    u32 len;
+    const u8 *m = msg_ptr(mv, i, len);
+    const sc256 e = ld_sc(sig + 49);
+    if (ws == 0) {   // stage the inputs, canonical-limb checks (the reference panics on these: src/batch.rs:67,104)
+        bool ok = true;
+        if (lane < 12) {
+            const u32 c = lane % 6u;
+            const u64 xs = ld_u64_le(sig + 8 * c), px = ld_u64_le(pk + 8 * c), py = ld_u64_le(pk + 48 + 8 * c);
+            coop_store7(L, SX, xs, lane);
+            coop_store7(L, PX, px, lane);
+            coop_store7(L, PY, py, lane);
+            ok = px < FP_P && py < FP_P && xs < FP_P;
+        }
+        ok = __all(ok) && !sc_geq_q(e);
+        if (lane == 0) {
+            sh.ok = ok;
+            sh.r_ok = 0;
+            sh.r_inf = 0;
+        }
+    }
+    __syncthreads();
+    // wave 0's share of R: decompression (one lane: the Fp6 square root is a long serial chain either way) and the
+    // table of its multiples.  With 128-bit coefficients [s]R is half a ladder and all of this fits beside wave 1's
+    // [s h]P; with full-width coefficients (a shim passing Scalar::random) both ladders are equally long and R's table
+    // is built BEFORE the first barrier instead, beside wave 1's hash.
+    const bool wide = coeff_bytes > 16;
+    auto r_tables = [&]() {
+        if (lane == 0) {   // R = from_compressed(sig.x).unwrap() (:104)
+            aff R;
+            bool r_inf = false;
+            const u32 st = decompress_lane(sig, R, r_inf);
+            sh.r_ok = st == 0;
+            sh.r_inf = r_inf;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                L.slot[RX][c] = R.x.c[c];
+                L.slot[RX][6 + c] = fp_mul_small(R.x.c[c], 7u);
+                L.slot[RY][c] = R.y.c[c];
+                L.slot[RY][6 + c] = fp_mul_small(R.y.c[c], 7u);
+            }
+        }
+        coop_sync();
+        if (sh.r_ok) coop_build_table(L, sh.r_inf != 0, lane, ws, TAB2, RX, RY);   // (lane 0 wrote it before the fence)
+    };
+    if (ws == 0) {
+        bool ok = sh.ok != 0;
+        if (ok && !inf) {   // y^2 == x^3 + x + (u + 395)
+            coop_mul(L, T0, PX, PX, lane, ws);
+            coop_mul(L, T0, T0, PX, lane, ws);
+            coop_add(L, T0, T0, PX, lane, ws);
+            if (lane < 2) L.slot[T0][lane] = fp_add(L.slot[T0][lane], lane == 0 ? 395ull : 1ull);   // compared only
+            coop_sync();
+            coop_mul(L, T0 + 1, PY, PY, lane, ws);
+            ok = coop_eq(L, T0, T0 + 1, lane, ws);
+        }
+        if (lane == 0) sh.ok = ok;
+        if (ok) {
+            coop_build_table(L, inf, lane, ws);
+            if (wide) r_tables();
+        }
+    } else {
+        const sc256 h = coop_hash_message(L, prm, m, len, lane, ws);   // reads SX, PX, PY only; h_i, src/batch.rs:64-73
+        if (lane == 0) {
+            sc256 s;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s.w[k] = 0;
+            const u8 *cp = coeffs + (size_t)coeff_bytes * i;
+            for (u32 b = 0; b < coeff_bytes; b++) s.w[b >> 3] |= (u64)cp[b] << (8 * (b & 7u));
+            s = sc_reduce256(s);                                       // Scalar::random, :75-78
+            const sc256 sb = sc_mul_mod(s, h), se = sc_mul_mod(s, e);  // :109-111, :92-97
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sh.s[k] = s.w[k];
+                sh.b[k] = sb.w[k];
+                sh.se[k] = se.w[k];
+            }
+        }
+    }
+    __syncthreads();
+    if (!sh.ok) {   // block-uniform
+        if (threadIdx.x < 24) rec[threadIdx.x] = threadIdx.x == 22 ? 1ull : 0ull;
+        return;
+    }
+    if (ws == 0) {
+        if (!wide) r_tables();
+        if (sh.r_ok) {
+            sc256 s;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s.w[k] = sh.s[k];
+            coop_mul_table(L, s, lane, ws, TAB2);                           // [s_i] R_i
+        }
+    } else {
+        sc256 b;
+#pragma unroll
+        for (int k = 0; k < 4; k++) b.w[k] = sh.b[k];
+        coop_mul_table(L, b, lane, ws);                                     // [s_i h_i] P_i  (the identity for an identity key)
+        coop_neg(L, AY, AY, lane, ws);                                      // k.0.neg(), :106
+    }
+    __syncthreads();
+    if (!sh.r_ok) {
+        if (threadIdx.x < 24) rec[threadIdx.x] = threadIdx.x == 22 ? 1ull : 0ull;
+        return;
+    }
+    if (ws == 0) {
+        // wave 1's accumulator as the second operand (X, Y, Z with their 7x halves) in this wave's I0..I2
+        if (lane < 18) {
+            const u32 v = lane / 6u, c = lane % 6u;
+            const u64 w = L.slot[WS_SLOTS + (int)v][c];
+            L.slot[I0 + (int)v][c] = w;
+            L.slot[I0 + (int)v][6 + c] = fp_mul_small(w, 7u);
+        }
+        coop_sync();
+        coop_jac_add(L, AX, I0, t, lane, ws);
+        if (lane < 18) rec[lane] = fp_canon(L.slot[AX + (int)(lane / 6u)][lane % 6u]);
+        else if (lane < 22) rec[lane] = sh.se[lane - 18u];
+        else if (lane < 24) rec[lane] = 0ull;
+    }
+}
+
+// records [g * group, (g + 1) * group) -> one record (one wave per group): the points by cooperative general
+// additions, the scalars mod q, the malformed flags OR-ed
+__global__ void __launch_bounds__(64)
+msm_k_sum_records(const u64 *__restrict__ in, u32 count, u32 group, u64 *__restrict__ out) {
+    __shared__ CoopLds L;
+    const u32 lane = threadIdx.x, g = blockIdx.x;
+    const u32 lo = g * group, hi = lo + group < count ? lo + group : count;
+    if (lo >= hi) return;
+    int t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = 7 + k;
+    bool bad = false;
+    sc256 lin;
+#pragma unroll
+    for (int k = 0; k < 4; k++) lin.w[k] = 0;
+    // accumulator 0..3 (X, Y, Z, W = Z^4), addend 4..6
+    auto load = [&](int s0, u32 j) {
+        if (lane < 36) {
+            const u32 v = lane / 12u, c = lane % 12u;
+            const u64 w = in[24 * (size_t)j + 6u * v + c % 6u];
+            L.slot[s0 + (int)v][c] = c < 6 ? w : fp_mul_small(w, 7u);
+        }
+        coop_sync();
+    };
+    load(0, lo);
+    coop_mul(L, 3, 2, 2, lane, 0);
+    coop_mul(L, 3, 3, 3, lane, 0);
+#pragma unroll 1
+    for (u32 j = lo; j < hi; j++) {
+        bad = bad || in[24 * (size_t)j + 22] != 0;
+        sc256 p;
+#pragma unroll
+        for (int k = 0; k < 4; k++) p.w[k] = in[24 * (size_t)j + 18 + k];
+        lin = sc_add_mod(lin, p);
+        if (j > lo) {
+            load(4, j);
+            coop_jac_add(L, 0, 4, t, lane, 0);
+        }
+    }
+    u64 *rec = out + 24 * (size_t)g;
+    if (lane < 18) rec[lane] = bad ? 0ull : fp_canon(L.slot[(int)(lane / 6u)][lane % 6u]);
+    else if (lane < 22) rec[lane] = lin.w[lane - 18u];
+    else if (lane == 22) rec[lane] = bad ? 1ull : 0ull;
+    else if (lane == 23) rec[lane] = 0ull;
+}
+
 }  // namespace ssa
 
 // ------------------------------------------------------------------------------------------------
@@ -453,6 +653,9 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
                    const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
                    const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out,
                    bool hashed = false);
+static int msm_run_small(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                         const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                         const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out);
 
 extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
                                            const uint8_t *d_pk_inf, const uint8_t *d_msgs,
@@ -462,6 +665,40 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
     if (!d_verdict_out) return SSA_ERR_ARG;
     return msm_run(ctx, d_sigs, d_pks, d_pk_inf, d_msgs, d_msg_off, msg_stride, msg_len, n, d_coeffs, coeff_bytes,
                    d_verdict_out, nullptr);
+}
+
+static int msm_combine_records(ssa_ctx *ctx, const u64 *d_records, size_t k, uint32_t *d_verdict_out, u64 *d_partial_out);
+
+// Small batch (n <= ctx->msm_small_max): one cooperative block per signature, then the records are summed -- in
+// groups of 16 by one wave each while there are more than 16 of them, the rest by the combination kernel, which also
+// computes [sum s_i e_i] G and compares (or emits the shard's record).
+static int msm_run_small(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                         const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                         const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out) {
+    const size_t groups = (n + 15) / 16;
+    if (ctx->msm_buckets.reserve(n * 24 * sizeof(u64)) || ctx->msm_chunks.reserve(groups * 24 * sizeof(u64)) ||
+        ctx->msm_windows.reserve(groups * 24 * sizeof(u64)))
+        return SSA_ERR_HIP;
+    MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
+    int rc = timed_launch(ctx, "msm_k_small", [&] {
+        hipLaunchKernelGGL(msm_k_small, dim3((unsigned)n), dim3(128), 0, ctx->stream, ctx->d_params, d_sigs, d_pks, d_pk_inf,
+                           mv, d_coeffs, coeff_bytes, n, (u64 *)ctx->msm_buckets.p);
+    });
+    if (rc) return rc;
+    const u64 *recs = (const u64 *)ctx->msm_buckets.p;
+    size_t count = n;
+    u64 *ping = (u64 *)ctx->msm_chunks.p, *pong = (u64 *)ctx->msm_windows.p;
+    while (count > 16) {     // the combination kernel adds its records one after the other: hand it at most 16
+        const size_t g = (count + 15) / 16;
+        hipLaunchKernelGGL(msm_k_sum_records, dim3((unsigned)g), dim3(64), 0, ctx->stream, recs, (u32)count, 16u, ping);
+        HIP_TRY(hipGetLastError());
+        recs = ping;
+        u64 *tmp = ping;
+        ping = pong;
+        pong = tmp;
+        count = g;
+    }
+    return msm_combine_records(ctx, recs, count, d_verdict_out, d_partial_out);
 }
 
 // the kernels of one MSM-form batch on ctx->stream: a verdict (d_partial_out == nullptr) or this shard's partial sums
@@ -490,6 +727,8 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
         d_coeffs = (const uint8_t *)p;
         coeff_bytes = 16;
     }
+    if (n <= ctx->msm_small_max) return msm_run_small(ctx, d_sigs, d_pks, d_pk_inf, d_msgs, d_msg_off, msg_stride, msg_len, n,
+                                                      d_coeffs, coeff_bytes, d_verdict_out, d_partial_out);
     const MsmShape sh = msm_shape(n);
     const size_t npts = 2 * n, total = npts * sh.windows, nb = (size_t)sh.windows * sh.buckets;
     const unsigned n_blocks = grid_for(n, 256);
@@ -636,15 +875,13 @@ __global__ void msm_k_unpack_parts(const u64 *__restrict__ parts, u32 k, u64 *__
 
 // The shards added up on one device: one Jacobian addition per shard, the scalars mod q, [lin]G from the comb table and
 // the x-only comparison (src/batch.rs:98-100,123-129) -- msm_k_finish with no doublings between its "windows".
-extern "C" int ssa_msm_combine_device(ssa_ctx *ctx, const uint64_t *d_parts24, size_t k, uint32_t *d_verdict_out) {
-    if (!ctx || !d_parts24 || !d_verdict_out || k == 0 || k > 4096) return SSA_ERR_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+static int msm_combine_records(ssa_ctx *ctx, const u64 *d_records, size_t k, uint32_t *d_verdict_out, u64 *d_partial_out) {
     if (ctx->msm_comb_pts.reserve(18 * k * sizeof(u64)) || ctx->msm_comb_lins.reserve(4 * k * sizeof(u64)) ||
         ctx->msm_flags.reserve(64))
         return SSA_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(msm_k_unpack_parts, dim3(grid_for(k * 24, 256)), dim3(256), 0, ctx->stream, (const u64 *)d_parts24,
-                       (u32)k, (u64 *)ctx->msm_comb_pts.p, (u64 *)ctx->msm_comb_lins.p, (u32 *)ctx->msm_flags.p);
+    hipLaunchKernelGGL(msm_k_unpack_parts, dim3(grid_for(k * 24, 256)), dim3(256), 0, ctx->stream, d_records, (u32)k,
+                       (u64 *)ctx->msm_comb_pts.p, (u64 *)ctx->msm_comb_lins.p, (u32 *)ctx->msm_flags.p);
     HIP_TRY(hipGetLastError());
     MsmShape sh;
     sh.c = 0;
@@ -654,8 +891,14 @@ extern "C" int ssa_msm_combine_device(ssa_ctx *ctx, const uint64_t *d_parts24, s
     return timed_launch(ctx, "msm_combine", [&] {
         hipLaunchKernelGGL(msm_k_finish, dim3(1), dim3(128), 0, ctx->stream, (const u64 *)ctx->msm_comb_pts.p, sh,
                            (const u64 *)ctx->msm_comb_lins.p, (u32)k, (const u64 *)ctx->d_gtab,
-                           (const u32 *)ctx->msm_flags.p, d_verdict_out, (u64 *)nullptr);
+                           (const u32 *)ctx->msm_flags.p, d_verdict_out, d_partial_out);
     });
+}
+
+extern "C" int ssa_msm_combine_device(ssa_ctx *ctx, const uint64_t *d_parts24, size_t k, uint32_t *d_verdict_out) {
+    if (!ctx || !d_parts24 || !d_verdict_out || k == 0 || k > 4096) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return msm_combine_records(ctx, (const u64 *)d_parts24, k, d_verdict_out, nullptr);
 }
 
 extern "C" int ssa_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k) {

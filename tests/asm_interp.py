@@ -95,6 +95,8 @@ class Lane:
             ln = lines[pc]
             pc += 1
             if ln.endswith(":"):
+                self.visited = getattr(self, "visited", set())
+                self.visited.add(ln[:-1])      # labels passed (tests check that a crafted input took a cold path)
                 continue
             self.issued += 1
             if ln.startswith("s_nop"):

@@ -173,6 +173,10 @@ def test_generated_fp6_blocks_on_the_cpu():
             return [2**64 - 1] * 6
         if kind == "zero":
             return [0] * 6
+        if kind == "sparse":     # k 2^48 in one coefficient: products k k' 2^96 = -k k' -- the reductions' cold paths
+            out = [0] * 6
+            out[rnd.randrange(6)] = rnd.randrange(1, 2**16) << 48
+            return out
         return [rnd.randrange(2**64) for _ in range(6)]
 
     spec = {   # name -> (is square, second product, linear terms [(sign, c, operand)])
@@ -186,12 +190,15 @@ def test_generated_fp6_blocks_on_the_cpu():
         "f6_mul2_add_core_asm": (False, True, []),
         "f6_sqr_subx_sub2y_core_asm": (True, False, [(-1, 1, "x"), (-1, 2, "y")]),
     }
-    kinds = ["rand"] * 6 + ["edge"] * 4 + ["max", "zero"]
+    kinds = ["rand"] * 6 + ["edge"] * 4 + ["max", "zero"] + ["sparse"] * 6
+    cold_taken = 0
     for name, (is_sqr, two, terms) in spec.items():
         lines, outs, ins = blocks[name]
         for kind in kinds:
             arr = {"a": elem(kind), "b": elem("rand" if kind == "zero" else kind), "c": elem(kind), "d": elem("rand"),
                    "x": elem(kind), "y": elem("edge" if kind == "rand" else kind)}
+            if kind == "sparse":
+                arr["d"], arr["x"], arr["y"] = elem("sparse"), [0] * 6, [0] * 6
             # the pre-scaled operands the C++ wrappers hand over (any representative mod p is allowed: canonical here)
             arr["b7"] = [7 * t % P for t in arr["b"]]
             arr["d7"] = [7 * t % P for t in arr["d"]]
@@ -205,6 +212,7 @@ def test_generated_fp6_blocks_on_the_cpu():
             lane = ai.Lane(env, dummy_pairs=())
             # the opening multiplies write their (impossible) carry to s[0:1] and nobody reads it before it is rewritten
             e = lane.run(lines)
+            cold_taken += any(lb.endswith("_fix_%=") for lb in getattr(lane, "visited", ()))
             got = [(e["%%[r%dl]" % k] | (e["%%[r%dh]" % k] << 32)) % P for k in range(6)]
             want = _f6_mulmod(arr["a"], arr["a"] if is_sqr else arr["b"])
             if two:
@@ -212,6 +220,7 @@ def test_generated_fp6_blocks_on_the_cpu():
             for sign, c, an in terms:
                 want = [(w + sign * c * t) % P for w, t in zip(want, arr[an])]
             assert got == want, (name, kind)
+    assert cold_taken >= 12       # the sparse operands did take the reductions' cold path (negative result: - EPS there)
 
 
 def test_asm_blocks_declare_what_they_clobber():
@@ -221,7 +230,7 @@ def test_asm_blocks_declare_what_they_clobber():
     import re
     for path in (INC, F6_INC):
         txt = open(path).read()
-        for m in re.finditer(r"SSA_DEV void (\w+)\(.*?asm(?: volatile)?\(\n(.*?)\n        : (.*?)\n        :(.*?)\n        : (\".*?)\);", txt, re.S):
+        for m in re.finditer(r"SSA_DEV (?:void|u32) (\w+)\(.*?asm(?: volatile)?\(\n(.*?)\n        : (.*?)\n        :(.*?)\n        : (\".*?)\);", txt, re.S):
             name, body, clob = m.group(1), m.group(2), m.group(5)
             clobbers = set(re.findall(r'"(\w+)"', clob))
             if re.search(r'"s_(andn2|and|xor|or|sub|add|cmp)', body):
@@ -289,10 +298,13 @@ def test_generated_doubling_on_the_cpu():
                 hi = (2**32 - rnd.randrange(1, 64)) * pow(c, -1, 2**32) % 2**32
                 out.append((hi << 32) | rnd.choice([rnd.randrange(2**32), 0xFFFFFFFF, 0]))
             return out
+        if kind == "sparse":     # k 2^48 in the first coefficient only: Y^2, Z^2, Y * 2Z are -(small): the reductions' cold paths
+            return [rnd.randrange(1, 2**15) << 48] + [0] * 5
         return [rnd.randrange(2**64) for _ in range(6)]
 
     cold_seen = 0
-    for kind in ["rand"] * 3 + ["edge"] * 5 + ["max", "zero", "hi", "hi", "hi", "near", "near", "near"]:
+    red_cold = 0
+    for kind in ["rand"] * 3 + ["edge"] * 5 + ["max", "zero", "hi", "hi", "hi", "near", "near", "near", "sparse", "sparse", "sparse"]:
         for n in (1, 3):
             pt = [elem(kind), elem("rand" if kind == "zero" else kind), elem(kind)]
             lane = ai.Lane({"%[n]": n})
@@ -300,13 +312,15 @@ def test_generated_doubling_on_the_cpu():
                 for j in range(6):
                     lane.v[regs[j]], lane.v[regs[j] + 1] = val[j] & M32, val[j] >> 32
             lane.run(lines)
-            cold_seen += lane.issued > n * 3200
+            cold_seen += lane.issued > n * 3000
+            red_cold += any("red" in lb and lb.endswith("_fix_%=") for lb in getattr(lane, "visited", ()))
             got = [[(lane.v[r] | (lane.v[r + 1] << 32)) % P for r in regs] for regs in (gj.XR, gj.YR, gj.ZR)]
             want = pt
             for _ in range(n):
                 want = _jac_dbl_model(*want)
             assert got == [list(w) for w in want], (kind, n)
     assert cold_seen >= 6         # the cold paths did run
+    assert red_cold >= 6          # ... those of the reductions too (sparse operands)
 
 
 def _f6_sub(u, v):
