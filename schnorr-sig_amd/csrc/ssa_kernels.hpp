@@ -10,9 +10,10 @@
 // HBM layout: inputs stay in the caller's AoS byte records (81-B signatures, 96-B keys,
 // message bytes); per-lane intermediates live in the context workspace:
 //   ws_h    n x 4 u64       challenge scalars
-//   ws_tab  n x 8 x 32 u64  per-lane affine multiples 1P..8P (256-B rows: x, y in the first 128-B line, the
-//                           scratch of the batch normalisation in the second), lane-contiguous so that a
-//                           lane's gather of one entry is six 16-byte loads from one cache line
+//   ws_tab  n x 8 x 32 u64  per-lane affine multiples 1P..8P (256-B rows: x, y in the first 128-B line; the second
+//                           line is scratch of the batch normalisation and holds the NEGATIVE entry (x, -y) once the
+//                           table is finished), lane-contiguous so that a lane's gather of one entry -- of either
+//                           sign -- is six 16-byte loads from ONE cache line
 //   gtab    16 x 65536 x 12 u64 affine multiples d*2^(16w)*G (100 MB, Infinity-Cache resident)
 #pragma once
 #include "curve.hpp"
@@ -28,7 +29,9 @@ constexpr int PTAB_ENTRIES = 8;
 // a table row is 256 B = two 128-B lines: X, Y (affine x, y after the build) in the first -- a gather of the
 // ladder touches exactly one line -- and Z, prefix product of the build in the second
 constexpr int PTAB_ENTRY_U64 = 32, PTAB_Z = 16, PTAB_C = 22;
-constexpr int PTAB_NY = 16;     // finished table: -y in the slot Z occupied during the build (the ladder never negates)
+// finished table: the second 128-B line of a row holds the NEGATIVE of the entry, (x, -y): the ladder reads one line
+// per window whatever the digit's sign and never negates (round 2 kept only -y there: a negative digit touched both lines)
+constexpr int PTAB_NEG = 16, PTAB_NY = PTAB_NEG + 6;
 
 constexpr u32 ST_OK = 0, ST_INVALID_PK = 1, ST_INVALID_SIG = 2, ST_MALFORMED = 3;
 
@@ -267,6 +270,7 @@ SSA_DEV aff aff_from_slope(const fp6 &l, const fp6 &x1, const fp6 &y1, const fp6
 }
 SSA_DEV void st_tab_entry(u64 *__restrict__ row, const aff &a) {
     st_aff(row, a);
+    st_f6(row + PTAB_NEG, a.x);
     st_f6(row + PTAB_NY, f6_neg(a.y));
 }
 SSA_DEV bool build_ptab_affine(u64 *__restrict__ tab, const aff &p) {
@@ -314,10 +318,7 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
         z.x = f6_zero();
         z.y = f6_zero();
 #pragma unroll 1
-        for (int e = 0; e < PTAB_ENTRIES; e++) {
-            st_aff(tab + e * R, z);
-            st_f6(tab + e * R + PTAB_NY, z.y);
-        }
+        for (int e = 0; e < PTAB_ENTRIES; e++) st_tab_entry(tab + e * R, z);
         return;
     }
 #ifndef SSA_PTAB_JACOBIAN_ONLY
@@ -358,10 +359,9 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
             a.x = f6_zero();
             a.y = f6_zero();
         }
-        st_aff(tab + e * R, a);
-        st_f6(tab + e * R + PTAB_NY, f6_neg(a.y));
+        st_tab_entry(tab + e * R, a);
     }
-    st_f6(tab + PTAB_NY, f6_neg(p.y));
+    st_tab_entry(tab, p);
 }
 
 #include "qnaf.inc"
@@ -397,10 +397,10 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q =
 #ifdef SSA_JAC_ASM
         // one asm statement per window: `gap` doublings + the addition on the lanes with a non-zero digit; -y comes from
         // the table, so the loop body outside the statement is the digit, one address and six loads
-        const u64 *row = tab + (size_t)((mag ? mag : 1) - 1) * PTAB_ENTRY_U64;
+        const u64 *row = tab + (size_t)((mag ? mag : 1) - 1) * PTAB_ENTRY_U64 + (digit < 0 ? PTAB_NEG : 0);
         aff q;
         q.x = ld_f6(row);
-        q.y = ld_f6(row + (digit < 0 ? PTAB_NY : 6));
+        q.y = ld_f6(row + 6);
         if (!jac_window_asm(acc.X.c, acc.Y.c, acc.Z.c, q.x.c, q.y.c, (u32)mag, gap)) {
             if (digit != 0) acc = jac_madd(acc, q);      // exceptional inputs: the exact compiled addition
         }

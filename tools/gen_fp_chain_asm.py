@@ -94,22 +94,22 @@ def reduce_tail(c):
 
 
 def multiply(c, saved):
-    """X <- X * saved value (register pair name "V0".."V4"): four multiplies, operand-scanning with the addends in
-    zero-extended pairs (v[A+1] and v[C+1] hold 0), then the reduction"""
+    """X <- X * saved value (register pair name "V0".."V4"): four multiplies and four carry instructions, then the
+    reduction.  (x0 s1 + x1 s0 is a 65-bit sum: its carry k rides into the top product as the addend (0, k); the middle
+    sum is added to the halves of t0 and t3 with a three-instruction carry chain.  Round 2 assembled the columns with
+    five register moves and a 64-bit add: 10 instructions for the head, now 8.)"""
     g = regs(c)
-    X, T, A, U, H, C, E, V = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved]
+    X, T, A, U, H, C, E, V, S = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved], g["S"]
+    S2, S3 = S + 8, S + 16
     head = [
-        ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),              # t0 = x0 s0
-        ("v_mov_b32 v%d, v%d" % (A, T + 1), [], []),
-        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), DUMMY, X, V + 1, vp(A)), [], []),  # t1 = x0 s1 + hi(t0)
-        ("v_mov_b32 v%d, v%d" % (A, U), [], []),
-        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V, vp(A)), [], []),  # t2 = x1 s0 + lo(t1)
-        ("v_mov_b32 v%d, v%d" % (T + 1, H), [], []),                                       # lo = (lo(t0), lo(t2))
-        ("v_mov_b32 v%d, v%d" % (A, U + 1), [], []),
-        ("v_mov_b32 v%d, v%d" % (C, H + 1), [], []),
-        # hi(t1) + hi(t2) < 2^33 into the E pair (free until the reduction; v[A+1], v[C+1] must stay 0)
-        ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(A), vp(C)), [], []),
-        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V + 1, vp(E)), [], []),   # hi
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),                   # t0 = x0 s0
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(U), DUMMY, X, V + 1), [], []),               # x0 s1
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), sp(S), X + 1, V, vp(U)), [], [S]),      # mid = x0 s1 + x1 s0, carry k
+        ("v_cndmask_b32 v%d, 0, 1, %s" % (C + 1, sp(S)), [], []),                               # (0, k): v[C] stays 0
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V + 1, vp(C)), [], []),   # t3 = x1 s1 + k 2^32
+        ("v_add_co_u32 v%d, %s, v%d, v%d" % (T + 1, sp(S2), T + 1, U), [], [S2]),               # lo = (t0.lo, t0.hi + mid.lo)
+        ("v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (H, sp(S3), H, U + 1, sp(S2)), [], [S3]),      # hi.lo = t3.lo + mid.hi + carry
+        ("v_addc_co_u32 v%d, %s, 0, v%d, %s" % (H + 1, sp(S2), H + 1, sp(S3)), [], [S2]),       # hi.hi += carry (cannot overflow)
     ]
     return head + reduce_tail(c)
 
@@ -147,7 +147,7 @@ def emit_program(name, prog, doc):
     body = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
                           "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
     for g in (g0, g1):
-        body += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1)]
+        body += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % g["C"]]
     n_loop = 0
     counts = {"valu": 0, "nop": 0}
     sq_body = schedule([square(0), square(1)])
@@ -299,7 +299,7 @@ def generate():
     pre = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
                          "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
     for g in (g0, g1):
-        pre += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1)]
+        pre += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % g["C"]]
     pre += ["s_mov_b32 s26, %[n]"]
     for ln in pre:
         lines.append('        "%s\\n\\t"' % ln)
