@@ -31,7 +31,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     print("chunks=%s  ssa_verify_many %.2f ms (min of 5; %.2f M verifications/s)"
           % (os.environ.get("SSA_PIPELINE_CHUNKS", "default"), min(ts) * 1e3, n / min(ts) / 1e6))
     if os.environ.get("SSA_PIPELINE_CHUNKS", "") == "4":
-        hip = C.CDLL("libamdhip64.so")
+        hip = C.CDLL("libamdhip64.so.7")      # the SONAME: the runtime this process has already loaded, not a second copy
         hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
         hip.hipHostUnregister.argtypes = [C.c_void_p]
         for name, a in (("sigs", sigs), ("pks", pks), ("msgs", msgs)):
