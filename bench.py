@@ -277,7 +277,7 @@ def plumbing_only(args, rk):
     elapsed = rk.max_over_ranks(time.perf_counter() - t0)
     devices = rk.device_report()
     if rk.rank == 0:
-        print(json.dumps({"metric": "plumbing only (no GPU work, not a measurement)", "value": 0.0,
+        emit(json.dumps({"metric": "plumbing only (no GPU work, not a measurement)", "value": 0.0,
                           "unit": "verifications/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
                           "scaling": "weak", "plumbing_only": True, "backend": rk.backend,
@@ -330,12 +330,35 @@ def distribute(rk, full, total, how):
     return out, ms
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a five-line version
+    banner at the first communicator, gloo its rank chatter): from here on file descriptor 1 points at stderr, and only
+    emit() writes to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    data = (line + "\n").encode()
+    fd = _REAL_STDOUT if _REAL_STDOUT is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args))
+        sys.exit(launch_ranks(args))      # (the ranks inherit the real stdout)
+    quiet_stdout()
 
     rk = Ranks(args)
     if args.plumbing_only:
@@ -594,7 +617,7 @@ def main():
 
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(np, sigs, pks, msgs, status_batch_semantics, min(args.cpu_sample, n))
-        print(json.dumps(out))
+        emit(json.dumps(out))
     rk.finish()
 
 

@@ -21,6 +21,9 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    # ... and nothing else on stdout: the chatter of the libraries below (gloo's rank lines here, RCCL's version banner on
+    # a GPU node) is kept on stderr
+    assert r.stdout.strip() == lines[0], r.stdout[:500]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["plumbing_only"] is True
     assert out["value"] == 0.0                      # plumbing only: never a measurement

@@ -50,6 +50,7 @@ def _bench(args, timeout=900):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
+    assert r.stdout.strip() == lines[0], "stdout must hold the JSON line only (RCCL's banner belongs on stderr): " + r.stdout[:300]
     return json.loads(lines[0])
 
 
