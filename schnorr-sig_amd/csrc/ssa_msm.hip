@@ -132,12 +132,24 @@ msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 
 }
 
 // ---- 2. sort keys ------------------------------------------------------------------------------
-__global__ void msm_k_digits(const u64 *__restrict__ scalars, size_t npts, MsmShape sh,
+// The first n points (the R_i) carry the coefficients s_i themselves: with coefficients of `coeff_bytes` bytes only
+// their lowest wa windows can be non-zero, and the sort is spared the rest (a quarter of the items for the 128-bit
+// coefficients the library draws); the other n points (the P_i) carry s_i h_i mod q and occupy every window.
+__global__ void msm_k_digits(const u64 *__restrict__ scalars, size_t n, u32 wa, MsmShape sh,
                              u32 *__restrict__ keys, u32 *__restrict__ vals) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= npts * sh.windows) return;
-    const u32 j = (u32)(t / npts);
-    const size_t i = t - (size_t)j * npts;
+    const size_t first = n * wa;
+    if (t >= first + n * sh.windows) return;
+    u32 j;
+    size_t i;
+    if (t < first) {
+        j = (u32)(t / n);
+        i = t - (size_t)j * n;
+    } else {
+        const size_t u = t - first;
+        j = (u32)(u / n);
+        i = n + (u - (size_t)j * n);
+    }
     const u32 d = sc_window(scalars + 4 * i, j * sh.c, sh.c);
     keys[t] = j * sh.buckets + d;
     vals[t] = (u32)i;
@@ -201,13 +213,14 @@ msm_k_chunks(const u64 *__restrict__ bsum, MsmShape sh, u64 *__restrict__ chunk_
         running = jac_add(running, b);
         total = jac_add(total, running);
     }
-    // + [v0 - 1] running (v0 >= 1 here unless this is the first chunk, where the weight offset is 0)
+    // + [v0 - 1] running (v0 >= 1 here unless this is the first chunk, where the weight offset is 0): double-and-add from
+    // the top set bit of the weight, the doublings through the ladder's generated statement
     if (v0 > 1) {
         const u32 m = v0 - 1;
-        jac acc = jac_identity();
+        jac acc = running;
 #pragma unroll 1
-        for (int bit = 15; bit >= 0; bit--) {
-            acc = jac_dbl(acc);
+        for (int bit = 30 - __builtin_clz(m); bit >= 0; bit--) {
+            acc = jac_dbl_n(acc, 1u);
             if ((m >> bit) & 1u) acc = jac_add(acc, running);
         }
         total = jac_add(total, acc);
@@ -730,7 +743,9 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
     if (n <= ctx->msm_small_max) return msm_run_small(ctx, d_sigs, d_pks, d_pk_inf, d_msgs, d_msg_off, msg_stride, msg_len, n,
                                                       d_coeffs, coeff_bytes, d_verdict_out, d_partial_out);
     const MsmShape sh = msm_shape(n);
-    const size_t npts = 2 * n, total = npts * sh.windows, nb = (size_t)sh.windows * sh.buckets;
+    // windows the coefficients themselves can reach (they are reduced mod q when they are as wide as q)
+    const u32 wa = coeff_bytes >= 32 ? sh.windows : (8u * coeff_bytes + sh.c - 1) / sh.c;
+    const size_t npts = 2 * n, total = n * wa + n * sh.windows, nb = (size_t)sh.windows * sh.buckets;
     const unsigned n_blocks = grid_for(n, 256);
     size_t sort_tmp = 0;
     const int end_bit = 32 - __builtin_clz((unsigned)(nb - 1) | 1u);
@@ -769,7 +784,7 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
     if (rc) return rc;
     rc = timed_launch(ctx, "msm_sort", [&] {
         hipLaunchKernelGGL(msm_k_digits, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream,
-                           (const u64 *)ctx->msm_scalars.p, npts, sh, (u32 *)ctx->msm_keys.p, (u32 *)ctx->msm_vals.p);
+                           (const u64 *)ctx->msm_scalars.p, n, wa, sh, (u32 *)ctx->msm_keys.p, (u32 *)ctx->msm_vals.p);
         (void)hipcub::DeviceRadixSort::SortPairs(ctx->msm_sort_tmp.p, sort_tmp, (const u32 *)ctx->msm_keys.p,
                                                  (u32 *)ctx->msm_keys2.p, (const u32 *)ctx->msm_vals.p,
                                                  (u32 *)ctx->msm_vals2.p, (int)total, 0, end_bit, ctx->stream);
