@@ -49,6 +49,12 @@ def regs(c):
     return g
 
 
+# the head of the 64x64 product.  "moves" (default): operand scanning, five register moves + one 64-bit add between the
+# four multiplies (10 instructions); "carries" (SSA_GEN_MUL_HEAD=carries): four carry instructions instead (8).  Measured
+# on one box, alternating (profiles/r03/mul_head_ab.txt): ssa_k_hash 8.36 / 8.39 / 8.40 ms with the moves against
+# 8.48 / 8.52 / 8.55 ms with the carry chain -- v_mov_b32 issues at twice the rate of the instructions that write or read
+# an SGPR carry, so the longer head is the faster one.
+MOVES_HEAD = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "carries"
 DUMMY = "s[24:25]"     # carry-outs nobody reads
 STICKY = 40            # s[40:41] / s[42:43]: lanes of chain 0 / 1 whose reduction met the rare borrow (see the docstring)
 SGPRS = list(range(20, 32)) + list(range(36, 44))
@@ -94,13 +100,26 @@ def reduce_tail(c):
 
 
 def multiply(c, saved):
-    """X <- X * saved value (register pair name "V0".."V4"): four multiplies and four carry instructions, then the
-    reduction.  (x0 s1 + x1 s0 is a 65-bit sum: its carry k rides into the top product as the addend (0, k); the middle
-    sum is added to the halves of t0 and t3 with a three-instruction carry chain.  Round 2 assembled the columns with
-    five register moves and a 64-bit add: 10 instructions for the head, now 8.)"""
+    """X <- X * saved value (register pair name "V0".."V4"): four multiplies, operand-scanning with the addends in
+    zero-extended pairs (v[A+1] and v[C+1] hold 0), then the reduction.  The alternative below the early return -- the
+    65-bit middle sum's carry k riding into the top product as the addend (0, k), a three-instruction carry chain for the
+    halves: 8 instructions instead of 10 -- measured slower (see MOVES_HEAD)."""
     g = regs(c)
     X, T, A, U, H, C, E, V, S = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved], g["S"]
     S2, S3 = S + 8, S + 16
+    if MOVES_HEAD:
+        return [
+            ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),
+            ("v_mov_b32 v%d, v%d" % (A, T + 1), [], []),
+            ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), DUMMY, X, V + 1, vp(A)), [], []),
+            ("v_mov_b32 v%d, v%d" % (A, U), [], []),
+            ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V, vp(A)), [], []),
+            ("v_mov_b32 v%d, v%d" % (T + 1, H), [], []),
+            ("v_mov_b32 v%d, v%d" % (A, U + 1), [], []),
+            ("v_mov_b32 v%d, v%d" % (C, H + 1), [], []),
+            ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(A), vp(C)), [], []),       # v[A+1], v[C+1] hold 0
+            ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V + 1, vp(E)), [], []),
+        ] + reduce_tail(c)
     head = [
         ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),                   # t0 = x0 s0
         ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(U), DUMMY, X, V + 1), [], []),               # x0 s1
@@ -147,7 +166,7 @@ def emit_program(name, prog, doc):
     body = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
                           "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
     for g in (g0, g1):
-        body += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % g["C"]]
+        body += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1 if MOVES_HEAD else g["C"])]
     n_loop = 0
     counts = {"valu": 0, "nop": 0}
     sq_body = schedule([square(0), square(1)])
@@ -299,7 +318,7 @@ def generate():
     pre = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
                          "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
     for g in (g0, g1):
-        pre += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % g["C"]]
+        pre += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1 if MOVES_HEAD else g["C"])]
     pre += ["s_mov_b32 s26, %[n]"]
     for ln in pre:
         lines.append('        "%s\\n\\t"' % ln)
