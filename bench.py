@@ -5,8 +5,10 @@ A step = one pass of the hot path (hash_message -> [h]P + [e]G -> x-compare -> w
 aggregate) over one batch of synthetic signatures per GPU, inputs resident in HBM.
 Workload: SURVEY.md §8(d) config 3 (random keypairs, one signature each, distinct 80-byte
 messages), generated on the GPU by the engine's own keygen/sign kernel.  Semantics of the
-headline number: verify_batch (src/batch.rs: no torsion check); the Signature::verify number
-(with the [q]P subgroup check, src/signature.rs:182) is reported beside it.
+headline number: verify_batch (src/batch.rs: no torsion check, R decompressed with the flag byte of
+sig.x -- flags = SSA_FLAG_SIG_FLAG_BYTE, exactly what ssa_verify_batch sets); the Signature::verify
+number (flags = SSA_FLAG_CHECK_TORSION: the [q]P subgroup check, src/signature.rs:182, flag byte
+ignored) is reported beside it.  The CPU leg runs the headline's flags.
 
 Multi-GPU: one process per GPU over RCCL.  The batch shards by signature, no data-path
 collective; the only exchange is one 8-byte all-reduce of the rejection counts per step.
@@ -197,7 +199,6 @@ class Ranks:
                 os.environ.setdefault("MASTER_PORT", str(free_port()))
                 os.environ.setdefault("RANK", "0")
                 os.environ.setdefault("WORLD_SIZE", "1")
-                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if self.backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
                                         device_id=torch.device("cuda", self.dev_index))
@@ -228,15 +229,18 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def msm_verdict(self, record, combine):
+    def msm_verdict(self, record, combine, engine):
         """MSM-form verdict over the ranks (schnorr_sig_amd.sharding.msm_verdict): all-gather of the 24-word shard
-        records on the device (RCCL), or through the host for the rehearsal backend"""
+        records on the device (RCCL), or through the host for the rehearsal backend.  `engine` produced `record`:
+        msm_verdict orders its stream against the collective's"""
         from schnorr_sig_amd.sharding import msm_verdict
         if self.on_device_collectives:
-            return msm_verdict(record, self.world, self.dist, combine)[0]
-        self.torch.cuda.current_stream().synchronize()
+            return msm_verdict(record, self.world, self.dist, combine, engine=engine)[0]
+        engine.sync()
         _, recs = msm_verdict(record.cpu(), self.world, self.dist, lambda r: None)
-        return combine(recs.to(record.device))
+        dev_recs = recs.to(record.device)
+        engine.stream_acquire(self.torch.cuda.current_stream().cuda_stream)
+        return combine(dev_recs)
 
     def sync_all(self):
         if self.dist is not None:
@@ -359,6 +363,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))      # (the ranks inherit the real stdout)
     quiet_stdout()
+    # read by the HSA runtime when it initialises: must be in the environment before the first torch.cuda call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     rk = Ranks(args)
     if args.plumbing_only:
@@ -414,9 +420,13 @@ def main():
     status = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
     nfail = torch.zeros(1, dtype=torch.int64, device=dev)
 
+    # The timed step runs exactly what ssa_verify_batch runs per signature (include/schnorr_sig_amd.h; reference
+    # src/batch.rs:56-130): no subgroup check, and R is the point the flag byte of sig.x selects (:104) --
+    # flags = SSA_FLAG_SIG_FLAG_BYTE.  The Signature::verify leg below runs flags = SSA_FLAG_CHECK_TORSION
+    # (src/signature.rs:181-205: subgroup check, flag byte ignored).
     def step(check_torsion=False):
         eng.verify_many_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, status.data_ptr(),
-                               nfail.data_ptr(), check_torsion=check_torsion)
+                               nfail.data_ptr(), check_torsion=check_torsion, sig_flag_byte=not check_torsion)
         rk.all_reduce_sum(nfail)     # aggregate verdict of the sharded batch (RCCL, 8 bytes)
 
     for _ in range(args.warmup):
@@ -474,7 +484,7 @@ def main():
             else:
                 eng.verify_batch_msm_partial_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80,
                                                     coeffs.data_ptr(), 16, record.data_ptr())
-                rk.msm_verdict(record, combine)
+                rk.msm_verdict(record, combine, eng)
         msm_step()
         rk.sync_all()
         eng.enable_timing(True)
@@ -548,6 +558,9 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": workload, "signatures_per_gpu": n, "signatures_total": n_all, "message_bytes": 80,
+                       "flags": {"word": ssa.FLAG_SIG_FLAG_BYTE, "names": ["SSA_FLAG_SIG_FLAG_BYTE"],
+                                 "meaning": "what ssa_verify_batch sets: no subgroup check, byte 48 of the signature "
+                                            "honoured (src/batch.rs:104); the CPU leg runs the same flags"},
                        "parallelism": "shard%d" % world, "corrupt_fraction": args.corrupt,
                        "backend": rk.backend if rk.dist is not None else None,
                        "process_group": ("forced one-rank group (RCCL rehearsal)" if rk.forced else "torchrun ranks")
@@ -617,6 +630,10 @@ def main():
 
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(np, sigs, pks, msgs, status_batch_semantics, min(args.cpu_sample, n))
+        elif world > 1:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = ("the CPU leg is timed on rank 0 at N = 1 only (the N = 1 line of the same "
+                                        "run carries it); an N > 1 line has none by design")
         emit(json.dumps(out))
     rk.finish()
 
@@ -641,7 +658,7 @@ def strong_leg(rk, eng, total):
 
     def step():
         eng.verify_many_device(sigs.data_ptr(), pks.data_ptr(), msgs.data_ptr(), n, 80, status.data_ptr(),
-                               nfail.data_ptr(), check_torsion=False)
+                               nfail.data_ptr(), check_torsion=False, sig_flag_byte=True)
         rk.all_reduce_sum(nfail)
     step()
     rk.sync_all()
@@ -722,14 +739,15 @@ def cpu_baseline(np, sigs, pks, msgs, gpu_status_batch_semantics, m):
     hs, hp, hm = sigs[:m].cpu().numpy(), pks[:m].cpu().numpy(), msgs[:m].cpu().numpy()
     threads = orc.hw_threads()
     tc = time.perf_counter()
-    st = orc.verify_many(hs, hp, hm, check_torsion=False, threads=threads)
+    st = orc.verify_many(hs, hp, hm, check_torsion=False, sig_flag_byte=True, threads=threads)
     dt = time.perf_counter() - tc
     gpu_st = gpu_status_batch_semantics[:m].cpu().numpy()
     out = {
         "value": m / dt, "unit": "verifications/s", "cores": threads, "kind": "port",
         "sample": "first %d signatures of rank 0's batch, C restatement of the reference algorithm "
-                  "(oracle/schnorr_oracle.c, -O3 -march=native, OpenMP), verify_batch semantics "
-                  "(check_torsion off on both sides)" % m,
+                  "(oracle/schnorr_oracle.c, -O3 -march=native, OpenMP), verify_batch semantics: flags = "
+                  "SSA_FLAG_SIG_FLAG_BYTE on both sides (no subgroup check, flag byte of sig.x honoured)" % m,
+        "flags": 8,
         "agrees_with_gpu": bool((st == gpu_st).all()),
     }
     # the same restatement the way the reference runs it: one thread (it has no threading), per

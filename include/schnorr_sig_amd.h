@@ -28,8 +28,8 @@
  *   signature  81 B = R.x c0..c5 (6 x u64) | flag byte (ignored by verify, src/signature.rs:186)
  *                     | e (32 B, < q)
  *   public key 96 B = affine x c0..c5 | y c0..c5   (PublicKey.0 is an AffinePoint in memory,
- *                     src/public.rs:24; the 49-B compressed form needs an Fp6 sqrt and is a
- *                     "next" row)
+ *                     src/public.rs:24); the 49-B compressed wire form (src/public.rs:49-56) goes through
+ *                     ssa_decompress_many / ssa_compress_many, or directly into ssa_verify_keyed_many
  *   messages   either a dense array with a fixed stride, or concatenated bytes + (n+1) offsets
  *
  * Ownership: the caller owns every buffer for the duration of the call; the library keeps
@@ -97,6 +97,14 @@ void ssa_ctx_destroy(ssa_ctx *ctx);
 const char *ssa_strerror(int rc);
 /* the built-in blob (SSA_PARAMS_LENGTH bytes) */
 const void *ssa_default_params(void);
+/* Ordering against a stream of the caller WITHOUT a host synchronisation.  Every *_device entry point only ENQUEUES
+ * on the context's stream (its own non-blocking stream unless ssa_ctx_set_stream changed it): its outputs are valid for
+ * other streams only after one of ssa_ctx_sync, ssa_ctx_stream_release, or a shared stream.
+ *   ssa_ctx_stream_release(ctx, s): stream s waits for everything enqueued on the context so far (publish outputs to s);
+ *   ssa_ctx_stream_acquire(ctx, s): the context's stream waits for everything enqueued on s so far (inputs written on s,
+ *                                   e.g. by a collective, are visible to the next call on the context). */
+int ssa_ctx_stream_release(ssa_ctx *ctx, void *consumer_hip_stream);
+int ssa_ctx_stream_acquire(ssa_ctx *ctx, void *producer_hip_stream);
 /* make the context issue its work on an existing hipStream_t.  NULL = back to the context's own (non-blocking)
  * stream; to select the legacy null stream pass HIP's own handle for it, hipStreamLegacy (or hipStreamPerThread). */
 int ssa_ctx_set_stream(ssa_ctx *ctx, void *hip_stream);
@@ -258,13 +266,21 @@ int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, const uint8_t 
  * form, one point addition per shard + one compare", src/batch.rs:98-129): every rank reduces ITS shard to one
  * record of SSA_MSM_PARTIAL_WORDS u64 --
  *     words 0..17  the shard's left-hand point  sum s_i R_i - sum (s_i h_i) P_i  (Jacobian X, Y, Z, canonical limbs)
- *     words 18..21 sum s_i e_i mod q            word 22  non-zero: the shard holds an input the reference panics on
- *     word 23      reserved (0)
+ *     words 18..21 sum s_i e_i mod q            word 22  1: the shard holds an input the reference panics on, else 0
+ *     word 23      SSA_MSM_RECORD_MAGIC -- every record the library produces carries it, the empty shard's too
  * -- the ranks all-gather the records (24 words per rank: the only traffic), and ssa_msm_combine adds the k points
  * up (one Jacobian addition per shard), computes [sum]G from the comb table and compares x coordinates exactly as
- * the single-context call does.  An empty shard (n == 0) gives the all-zero record (the identity and 0).
- * Coefficients as in ssa_verify_batch_msm_device (NULL: drawn per call on the device; every rank draws its own). */
+ * the single-context call does.  An empty shard (n == 0) gives the identity (all limbs 0), 0 and the magic word.
+ * Coefficients as in ssa_verify_batch_msm_device (NULL: drawn per call on the device; every rank draws its own).
+ *
+ * ORDERING (the _device forms are asynchronous): ssa_verify_batch_msm_partial_device only enqueues on the context's
+ * stream; the record is valid for a collective on another stream after ssa_ctx_stream_release(ctx, that stream) (or
+ * ssa_ctx_sync, or a shared stream via ssa_ctx_set_stream), and the gathered records are visible to
+ * ssa_msm_combine_device after ssa_ctx_stream_acquire(ctx, the collective's stream).  The combination FAILS CLOSED:
+ * a record that was never written (all zero), comes from another format version, has a non-canonical limb or scalar,
+ * or a point off the curve makes the verdict SSA_MALFORMED -- never SSA_OK. */
 #define SSA_MSM_PARTIAL_WORDS 24
+#define SSA_MSM_RECORD_MAGIC 0x5353415245430004ull   /* "SSAREC", format 4 */
 int ssa_verify_batch_msm_partial_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
                                         const uint8_t *d_pk_inf, const uint8_t *d_msgs, const uint64_t *d_msg_off,
                                         size_t msg_stride, size_t msg_len, size_t n, const uint8_t *d_coeffs,
@@ -283,7 +299,7 @@ int ssa_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k);
  * Bumped whenever an exported signature changes (round 2 inserted pk_inf into the batch entry points under the same
  * symbol names: a shim built against the older header would still link and pass msgs as pk_inf).  A binding checks
  * ssa_abi_version() == SSA_ABI_VERSION at load; the Python and C++ mirrors do. */
-#define SSA_ABI_VERSION 3
+#define SSA_ABI_VERSION 4
 int ssa_abi_version(void);
 
 /* ---- arithmetic probes (unit parity with the oracle; not part of the reference API) --- */
@@ -302,6 +318,10 @@ int ssa_abi_version(void);
  *         the two generated blocks (non-zero: the block reported its rare reduction borrow and the lane was recomputed) */
 int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                     size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride);
+/* error-path tests: the next pipelined host-buffer upload on this context fails with SSA_ERR_HIP after chunk `chunk`
+ * has been enqueued (one shot; chunk < 0 disarms).  Replaces round 3's SSA_FAULT_AFTER_CHUNK environment variable: the
+ * production path reads no environment per call. */
+int ssa_debug_fault_after_chunk(ssa_ctx *ctx, int chunk);
 /* n_blocks 64-byte blocks of the ChaCha20 keystream the MSM coefficients come from (RFC 8439 known answers) */
 int ssa_debug_chacha20(ssa_ctx *ctx, const uint8_t key[32], const uint8_t nonce[12], uint32_t counter0,
                        size_t n_blocks, uint8_t *out);

@@ -140,6 +140,9 @@ def _load():
         "ssa_msm_combine_device": (i32, [vp, vp, sz, vp]),
         "ssa_msm_combine": (i32, [vp, vp, sz]),
         "ssa_abi_version": (i32, []),
+        "ssa_ctx_stream_release": (i32, [vp, vp]),
+        "ssa_ctx_stream_acquire": (i32, [vp, vp]),
+        "ssa_debug_fault_after_chunk": (i32, [vp, i32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here == ABI symbol missing: fail loudly
@@ -154,8 +157,9 @@ def _load():
     return lib, list(sigs)
 
 
-ABI_VERSION = 3        # SSA_ABI_VERSION of include/schnorr_sig_amd.h
+ABI_VERSION = 4        # SSA_ABI_VERSION of include/schnorr_sig_amd.h
 MSM_PARTIAL_WORDS = 24
+MSM_RECORD_MAGIC = 0x5353415245430004     # SSA_MSM_RECORD_MAGIC: word 23 of every shard record
 _lib, ABI_SYMBOLS = _load()
 
 
@@ -428,9 +432,26 @@ class Engine:
     def sync(self):
         _check(_lib.ssa_ctx_sync(self._ctx), "ssa_ctx_sync")
 
+    def stream_release(self, consumer_stream):
+        """stream `consumer_stream` (a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream) waits for
+        everything this engine has enqueued so far: its outputs become visible there without a host synchronisation"""
+        _check(_lib.ssa_ctx_stream_release(self._ctx, C.c_void_p(consumer_stream or 0)), "ssa_ctx_stream_release")
+
+    def stream_acquire(self, producer_stream):
+        """this engine's stream waits for everything enqueued on `producer_stream` so far (inputs written there, e.g.
+        by a collective, are visible to the next call on the engine)"""
+        _check(_lib.ssa_ctx_stream_acquire(self._ctx, C.c_void_p(producer_stream or 0)), "ssa_ctx_stream_acquire")
+
+    def debug_fault_after_chunk(self, chunk):
+        """tests: the NEXT pipelined host-buffer upload fails after chunk `chunk` (one shot; < 0 disarms)"""
+        _check(_lib.ssa_debug_fault_after_chunk(self._ctx, int(chunk)), "ssa_debug_fault_after_chunk")
+
     def verify_many_device(self, d_sigs, d_pks, d_msgs, n, msg_len, d_status, d_nfail, msg_stride=None,
-                           d_offsets=0, d_pk_inf=0, check_torsion=False, mode=None):
-        flags = (FLAG_CHECK_TORSION if check_torsion else 0) | _MODE_FLAGS[mode]
+                           d_offsets=0, d_pk_inf=0, check_torsion=False, mode=None, sig_flag_byte=False):
+        """sig_flag_byte=True with check_torsion=False is what ssa_verify_batch runs (src/batch.rs:104: R is decompressed
+        with the flag byte of sig.x, no subgroup check)"""
+        flags = (FLAG_CHECK_TORSION if check_torsion else 0) | _MODE_FLAGS[mode] | \
+            (FLAG_SIG_FLAG_BYTE if sig_flag_byte else 0)
         _check(_lib.ssa_verify_many_device(self._ctx, d_sigs, d_pks, d_pk_inf or None, d_msgs, d_offsets or None,
                                            msg_stride if msg_stride is not None else msg_len, msg_len, n,
                                            flags, d_status, d_nfail), "ssa_verify_many_device")
@@ -465,10 +486,10 @@ class Engine:
         device tensors are copied to ordinary pageable host arrays first, then `reps` timed calls."""
         import time
         hs, hp, hm = (t[:n].cpu().numpy() for t in (sigs_t, pks_t, msgs_t))
-        st, nf = self.verify_many(hs, hp, hm, check_torsion=False, mode="lane")     # warm-up: workspaces
+        st, nf = self.verify_many(hs, hp, hm, check_torsion=False, mode="lane", sig_flag_byte=True)     # warm-up: workspaces
         t0 = time.perf_counter()
         for _ in range(reps):
-            st, nf = self.verify_many(hs, hp, hm, check_torsion=False, mode="lane")
+            st, nf = self.verify_many(hs, hp, hm, check_torsion=False, mode="lane", sig_flag_byte=True)
         dt = (time.perf_counter() - t0) / reps
         verdict = self.verify_batch_msm(hs, hp, hm)                                  # MSM form, library-drawn coefficients
         t0 = time.perf_counter()

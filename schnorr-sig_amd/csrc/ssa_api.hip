@@ -92,6 +92,14 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         const int v = std::atoi(vb);
         if (v == 64 || v == 128 || v == 256) ctx->verify_block = (unsigned)v;
     }
+    if (const char *ls = std::getenv("SSA_LANE_SLICE")) {      // lanes per slice of the per-lane kernels (workspace bound)
+        const size_t v = (size_t)std::strtoull(ls, nullptr, 10);
+        if (v >= 256) ctx->lane_slice = v;
+    }
+    if (const char *ms = std::getenv("SSA_MSM_SLICE")) {       // signatures per slice of the MSM-form pipeline
+        const size_t v = (size_t)std::strtoull(ms, nullptr, 10);
+        if (v >= 256 && v <= ((size_t)1 << 25)) ctx->msm_slice = v;
+    }
     if (const char *pc = std::getenv("SSA_PIPELINE_CHUNKS")) {
         const int v = std::atoi(pc);
         if (v >= 1 && v <= 8) ctx->pipeline_chunks = (unsigned)v;
@@ -106,7 +114,8 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
             ssa_ctx_destroy(ctx);
             return SSA_ERR_HIP;
         }
-    if (hipEventCreateWithFlags(&ctx->pipe_start, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&ctx->pipe_start, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming) != hipSuccess) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
@@ -173,7 +182,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
                       &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
                       &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
-                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins})
+                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
@@ -182,6 +191,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
     for (auto &ev : ctx->hash_done)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->pipe_start) (void)hipEventDestroy(ctx->pipe_start);
+    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     for (auto &st : ctx->hash_stream)
         if (st) (void)hipStreamDestroy(st);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -195,6 +205,25 @@ extern "C" int ssa_ctx_set_stream(ssa_ctx *ctx, void *hip_stream) {
     if (!ctx) return SSA_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
+
+// Ordering between the context's stream and a stream of the caller, without a host synchronisation (one event each way).
+extern "C" int ssa_ctx_stream_release(ssa_ctx *ctx, void *consumer_stream) {
+    if (!ctx) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((hipStream_t)consumer_stream == ctx->stream) return 0;      // same stream: already ordered
+    HIP_TRY(hipEventRecord(ctx->order_ev, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, ctx->order_ev, 0));
+    return 0;
+}
+
+extern "C" int ssa_ctx_stream_acquire(ssa_ctx *ctx, void *producer_stream) {
+    if (!ctx) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((hipStream_t)producer_stream == ctx->stream) return 0;
+    HIP_TRY(hipEventRecord(ctx->order_ev, (hipStream_t)producer_stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->order_ev, 0));
     return 0;
 }
 
@@ -300,6 +329,32 @@ extern "C" int ssa_verify_many_device(ssa_ctx *ctx, const uint8_t *d_sigs, const
                          d_fail);
 }
 
+// message view of the lanes from `lo` on (offsets are absolute into msgs: only the offset table moves)
+static inline MsgView msg_slice(const MsgView &mv, size_t lo) {
+    MsgView s = mv;
+    if (mv.off) s.off = mv.off + lo;
+    else if (mv.msgs) s.msgs = mv.msgs + lo * mv.stride;
+    return s;
+}
+
+// ssa_k_verify over n lanes whose challenge scalars are in d_h, in slices of at most ctx->lane_slice lanes: the 2 KB
+// per-lane table workspace never exceeds one slice (the caller has reserved it).  *d_fail is added to.
+static int verify_slices(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                         const u64 *d_h, size_t n, uint32_t flags, uint8_t *d_status_out, unsigned long long *d_fail) {
+    const size_t slice = ctx->lane_slice < n ? ctx->lane_slice : n;
+    for (size_t lo = 0; lo < n; lo += slice) {
+        const size_t cnt = n - lo < slice ? n - lo : slice;
+        int rc = timed_launch(ctx, "ssa_k_verify", [&] {
+            hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(cnt, ctx->verify_block)), dim3(ctx->verify_block), 0,
+                               ctx->stream, d_sigs + 81 * lo, d_pks + 96 * lo, d_pk_inf ? d_pk_inf + lo : nullptr,
+                               d_h + 4 * lo, (const u64 *)ctx->d_gtab, (u64 *)ctx->ws_tab.p, cnt, flags,
+                               d_status_out + lo, d_fail);
+        });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // the kernels of one verification batch on ctx->stream; *d_fail is added to, not reset
 static int verify_launch(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
                          const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
@@ -314,18 +369,27 @@ static int verify_launch(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_p
                                d_pks, d_pk_inf, mv, (const u64 *)ctx->d_gtab, n, flags, d_status_out, d_fail);
         });
     }
-    if (ctx->ws_h.reserve(n * 4 * sizeof(u64))) return SSA_ERR_HIP;
-    if (ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
-    int rc = timed_launch(ctx, "ssa_k_hash", [&] {
-        hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
-                           d_sigs, d_pks, mv, n, (u64 *)ctx->ws_h.p, (u8 *)nullptr, (const u32 *)nullptr, 0u);
-    });
-    if (rc) return rc;
-    return timed_launch(ctx, "ssa_k_verify", [&] {
-        hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(n, ctx->verify_block)), dim3(ctx->verify_block), 0, ctx->stream, d_sigs, d_pks,
-                           d_pk_inf, (const u64 *)ctx->ws_h.p, (const u64 *)ctx->d_gtab,
-                           (u64 *)ctx->ws_tab.p, n, flags, d_status_out, d_fail);
-    });
+    // The per-lane workspaces (32 B of challenge scalar, 2 KB of table) are sized for ONE slice of at most
+    // ctx->lane_slice lanes, whatever n is (2.1 GB of tables at the default 2^20; the reference takes slices of any
+    // length, src/batch.rs:31-50): a larger batch runs slice after slice on the stream, into the caller's one status
+    // array and the one rejection counter.  At n <= lane_slice this is the single pair of launches it always was.
+    const size_t slice = ctx->lane_slice < n ? ctx->lane_slice : n;
+    if (ctx->ws_h.reserve(slice * 4 * sizeof(u64))) return SSA_ERR_HIP;
+    if (ctx->ws_tab.reserve(slice * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
+    for (size_t lo = 0; lo < n; lo += slice) {
+        const size_t cnt = n - lo < slice ? n - lo : slice;
+        const MsgView smv = msg_slice(mv, lo);
+        int rc = timed_launch(ctx, "ssa_k_hash", [&] {
+            hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(cnt, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                               d_sigs + 81 * lo, d_pks + 96 * lo, smv, cnt, (u64 *)ctx->ws_h.p, (u8 *)nullptr,
+                               (const u32 *)nullptr, 0u);
+        });
+        if (rc) return rc;
+        rc = verify_slices(ctx, d_sigs + 81 * lo, d_pks + 96 * lo, d_pk_inf ? d_pk_inf + lo : nullptr,
+                           (const u64 *)ctx->ws_h.p, cnt, flags, d_status_out + lo, d_fail);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces,
@@ -366,17 +430,16 @@ static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_
     if (!pin.r_status.pin(status_out, n)) return 0;
     if (int rc = pipelined_upload_hash(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, pin, used)) return rc;
     if (!*used) return 0;
+    const size_t slice = ctx->lane_slice < n ? ctx->lane_slice : n;
     if (ctx->st_status.reserve(n + 16) ||
-        ctx->ws_tab.reserve(n * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64)))
+        ctx->ws_tab.reserve(slice * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64)))
         return SSA_ERR_HIP;
     unsigned long long *d_fail = (unsigned long long *)ctx->ws_fail.p;
     HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned long long), ctx->stream));
-    int rc = timed_launch(ctx, "ssa_k_verify", [&] {
-        hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(n, ctx->verify_block)), dim3(ctx->verify_block), 0, ctx->stream,
-                           pin.s.sigs, pin.s.pks, pin.s.inf, (const u64 *)ctx->ws_h.p,
-                           (const u64 *)ctx->d_gtab, (u64 *)ctx->ws_tab.p, n, flags, (u8 *)ctx->st_status.p, d_fail);
-    });
-    if (rc) return rc;
+    // (the pipeline hashed the whole batch into ws_h, 32 B per lane, while it was uploading)
+    if (int rc = verify_slices(ctx, pin.s.sigs, pin.s.pks, pin.s.inf, (const u64 *)ctx->ws_h.p, n, flags,
+                               (u8 *)ctx->st_status.p, d_fail))
+        return rc;
     HIP_TRY(hipMemcpyAsync(status_out, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
     unsigned long long nf = 0;
     HIP_TRY(hipMemcpyAsync(&nf, d_fail, sizeof nf, hipMemcpyDeviceToHost, ctx->stream));
@@ -822,7 +885,7 @@ extern "C" int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, con
     for (size_t r = 0; r < world; r++) {
         const size_t lo = r * base + (r < rem ? r : rem), cnt = base + (r < rem ? 1 : 0);
         threads.emplace_back([&, r, lo, cnt] {
-            if (cnt == 0) return;
+            // (an empty shard still produces its record -- the identity, 0 and the magic word: an unwritten slot is not one)
             std::vector<uint64_t> off;
             const uint8_t *mbase = msgs;
             const uint64_t *offp = nullptr;
@@ -846,6 +909,12 @@ extern "C" int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, con
 }
 
 // ------------------------------------------------------------------ probes
+extern "C" int ssa_debug_fault_after_chunk(ssa_ctx *ctx, int chunk) {
+    if (!ctx) return SSA_ERR_ARG;
+    ctx->fault_after_chunk = chunk;
+    return 0;
+}
+
 extern "C" int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, size_t n,
                                size_t a_stride, size_t b_stride, uint64_t *out, size_t out_stride) {
     if (!ctx || !a || !out || n == 0 || op < 0 || op > 18) return SSA_ERR_ARG;

@@ -64,6 +64,7 @@ struct ssa_ctx {
     hipStream_t hash_stream[2] = {};          // the chunks' hash launches alternate between two streams, so that the
     hipEvent_t hash_done[8] = {};             //   tail of one launch (a lane hashes for ~4 ms) overlaps the next
     hipEvent_t pipe_start = nullptr;          // everything queued on `stream` before a pipelined upload began
+    hipEvent_t order_ev = nullptr;            // ssa_ctx_stream_release / _acquire
     size_t pipeline_min_n = 1 << 17;          // host-buffer batches from this size on are uploaded in chunks
     unsigned pipeline_chunks = 8;             // SSA_PIPELINE_CHUNKS overrides (1 = off)
     DevParams *d_params = nullptr;
@@ -82,6 +83,12 @@ struct ssa_ctx {
     size_t coop_max_n = 7680, coop_max_n_torsion = 10496;   // lane kernels: 3.5 / 5.4 ms flat up to 2^15 (round 2, window asm)
     size_t msm_small_max = 3072;  // MSM-form batches up to this size: one cooperative block per signature (measured
                                   // crossover with the bucket method: tools/msm_small_crossover.py; SSA_MSM_SMALL_MAX)
+    int fault_after_chunk = -1;   // ssa_debug_fault_after_chunk (tests)
+    // Workspace bound: the per-lane kernels run over slices of at most lane_slice lanes (2 KB of table + 32 B of scalar
+    // each: 2.1 GB at 2^20), the MSM-form pipeline over slices of at most msm_slice signatures whose records are
+    // combined like the shards of a multi-GPU batch.  SSA_LANE_SLICE / SSA_MSM_SLICE override (tests force small ones).
+    size_t lane_slice = (size_t)1 << 20, msm_slice = (size_t)1 << 24;
+    DevBuf msm_slice_recs;        // one 24-word record per MSM slice
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;
     std::vector<struct ssa_keyset *> keysets;   // live key sets of this context (orphaned, not leaked, by ssa_ctx_destroy)
@@ -202,11 +209,12 @@ struct PipelinedInputs {
     }
 };
 
-// debug hook of the error-path tests: SSA_FAULT_AFTER_CHUNK=k makes the pipelined upload fail (SSA_ERR_HIP) after
-// chunk k has been enqueued
-static inline int pipeline_fault_chunk() {
-    const char *e = std::getenv("SSA_FAULT_AFTER_CHUNK");
-    return e ? std::atoi(e) : -1;
+// debug hook of the error-path tests (ssa_debug_fault_after_chunk): the next pipelined upload fails (SSA_ERR_HIP) after
+// chunk k has been enqueued.  One shot, armed through the ABI on this context only: no environment is read per call.
+static inline int pipeline_fault_chunk(ssa_ctx *ctx) {
+    const int k = ctx->fault_after_chunk;
+    ctx->fault_after_chunk = -1;
+    return k;
 }
 
 // Uploads of a large host-buffer batch in chunks on the copy stream; the challenge hashes of chunk c start as soon as
@@ -238,7 +246,7 @@ static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const
     HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_start, 0));
     for (auto &hs : ctx->hash_stream) HIP_TRY(hipStreamWaitEvent(hs, ctx->pipe_start, 0));
     pin.armed = ctx;
-    const int fault_chunk = pipeline_fault_chunk();
+    const int fault_chunk = pipeline_fault_chunk(ctx);
     const u64 *d_off = nullptr;
     if (msg_off) {
         HIP_TRY(hipMemcpyAsync(ctx->st_off.p, msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy_stream));

@@ -298,9 +298,11 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
     const u32 lane = threadIdx.x & 63u;
     const int ws = (int)(threadIdx.x >> 6);
     if (*malformed) {   // block-uniform
-        if (threadIdx.x == 0) {
-            if (partial_out) partial_out[22] = 1;
-            else *verdict = ST_MALFORMED;
+        if (partial_out) {   // a whole, well-formed record: no word is left to whatever the buffer held before
+            if (threadIdx.x < 24)
+                partial_out[threadIdx.x] = threadIdx.x == 22 ? 1ull : threadIdx.x == 23 ? SSA_MSM_RECORD_MAGIC : 0ull;
+        } else if (threadIdx.x == 0) {
+            *verdict = ST_MALFORMED;
         }
         return;
     }
@@ -385,7 +387,7 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
         if (ws == 0 && lane < 18) partial_out[lane] = fp_canon(L.slot[(int)(lane / 6u)][lane % 6u]);
         if (threadIdx.x == 0) {
             partial_out[22] = 0;
-            partial_out[23] = 0;
+            partial_out[23] = SSA_MSM_RECORD_MAGIC;
         }
         return;
     }
@@ -521,7 +523,7 @@ msm_k_small(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs, cons
     }
     __syncthreads();
     if (!sh.ok) {   // block-uniform
-        if (threadIdx.x < 24) rec[threadIdx.x] = threadIdx.x == 22 ? 1ull : 0ull;
+        if (threadIdx.x < 24) rec[threadIdx.x] = threadIdx.x == 22 ? 1ull : threadIdx.x == 23 ? SSA_MSM_RECORD_MAGIC : 0ull;
         return;
     }
     if (ws == 0) {
@@ -541,7 +543,7 @@ msm_k_small(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs, cons
     }
     __syncthreads();
     if (!sh.r_ok) {
-        if (threadIdx.x < 24) rec[threadIdx.x] = threadIdx.x == 22 ? 1ull : 0ull;
+        if (threadIdx.x < 24) rec[threadIdx.x] = threadIdx.x == 22 ? 1ull : threadIdx.x == 23 ? SSA_MSM_RECORD_MAGIC : 0ull;
         return;
     }
     if (ws == 0) {
@@ -556,7 +558,8 @@ msm_k_small(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs, cons
         coop_jac_add(L, AX, I0, t, lane, ws);
         if (lane < 18) rec[lane] = fp_canon(L.slot[AX + (int)(lane / 6u)][lane % 6u]);
         else if (lane < 22) rec[lane] = sh.se[lane - 18u];
-        else if (lane < 24) rec[lane] = 0ull;
+        else if (lane == 22) rec[lane] = 0ull;
+        else if (lane == 23) rec[lane] = SSA_MSM_RECORD_MAGIC;
     }
 }
 
@@ -603,7 +606,13 @@ msm_k_sum_records(const u64 *__restrict__ in, u32 count, u32 group, u64 *__restr
     if (lane < 18) rec[lane] = bad ? 0ull : fp_canon(L.slot[(int)(lane / 6u)][lane % 6u]);
     else if (lane < 22) rec[lane] = lin.w[lane - 18u];
     else if (lane == 22) rec[lane] = bad ? 1ull : 0ull;
-    else if (lane == 23) rec[lane] = 0ull;
+    else if (lane == 23) rec[lane] = SSA_MSM_RECORD_MAGIC;
+}
+
+// the record of an empty shard: the identity (Z = 0), sum s_i e_i = 0, not malformed -- and the magic word: a buffer that
+// nobody wrote (all zero) is NOT a record
+__global__ void msm_k_empty_record(u64 *__restrict__ rec) {
+    if (threadIdx.x < 24) rec[threadIdx.x] = threadIdx.x == 23 ? SSA_MSM_RECORD_MAGIC : 0ull;
 }
 
 }  // namespace ssa
@@ -666,6 +675,10 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
                    const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
                    const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out,
                    bool hashed = false);
+static int msm_run_one(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                       const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                       const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out,
+                       const u64 *d_h);
 static int msm_run_small(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
                          const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
                          const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out);
@@ -680,7 +693,9 @@ extern "C" int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, 
                    d_verdict_out, nullptr);
 }
 
-static int msm_combine_records(ssa_ctx *ctx, const u64 *d_records, size_t k, uint32_t *d_verdict_out, u64 *d_partial_out);
+// check_points: the records come from outside this call (ssa_msm_combine*): scalars and points are validated too
+static int msm_combine_records(ssa_ctx *ctx, const u64 *d_records, size_t k, uint32_t *d_verdict_out, u64 *d_partial_out,
+                               bool check_points = false);
 
 // Small batch (n <= ctx->msm_small_max): one cooperative block per signature, then the records are summed -- in
 // groups of 16 by one wave each while there are more than 16 of them, the rest by the combination kernel, which also
@@ -714,8 +729,10 @@ static int msm_run_small(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_p
     return msm_combine_records(ctx, recs, count, d_verdict_out, d_partial_out);
 }
 
-// the kernels of one MSM-form batch on ctx->stream: a verdict (d_partial_out == nullptr) or this shard's partial sums
-// hashed: ctx->ws_h already holds the challenge scalars (the host-buffer pipeline computed them while uploading)
+// A batch of any size (n <= SSA_MAX_BATCH) in bounded memory: more than ctx->msm_slice signatures run slice after slice,
+// every slice reduced to its 24-word record exactly as a shard of a multi-GPU batch is (src/batch.rs:98-129: one point
+// and one scalar per part), and the records are added up by the combination kernel -- one point addition per slice.
+// hashed: ctx->ws_h already holds the challenge scalars of the WHOLE batch (the host-buffer pipeline computed them).
 static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
                    const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
                    const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out,
@@ -723,12 +740,38 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
     if (!ctx || (!d_verdict_out && !d_partial_out)) return SSA_ERR_ARG;
     if (n && (!d_sigs || !d_pks)) return SSA_ERR_ARG;
     if (d_coeffs && (coeff_bytes == 0 || coeff_bytes > 32)) return SSA_ERR_ARG;
-    if (n > (1ull << 25)) return SSA_ERR_ARG;   // 2n * 16 sort items must fit hipCUB's int item count
     if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    const u64 *d_h = hashed ? (const u64 *)ctx->ws_h.p : nullptr;
+    if (n <= ctx->msm_slice)
+        return msm_run_one(ctx, d_sigs, d_pks, d_pk_inf, d_msgs, d_msg_off, msg_stride, msg_len, n, d_coeffs, coeff_bytes,
+                           d_verdict_out, d_partial_out, d_h);
+    const size_t slice = ctx->msm_slice, k = (n + slice - 1) / slice;
+    if (ctx->msm_slice_recs.reserve(k * 24 * sizeof(u64))) return SSA_ERR_HIP;
+    u64 *recs = (u64 *)ctx->msm_slice_recs.p;
+    for (size_t j = 0; j < k; j++) {
+        const size_t lo = j * slice, cnt = n - lo < slice ? n - lo : slice;
+        if (int rc = msm_run_one(ctx, d_sigs + 81 * lo, d_pks + 96 * lo, d_pk_inf ? d_pk_inf + lo : nullptr,
+                                 d_msg_off ? d_msgs : (d_msgs ? d_msgs + lo * msg_stride : nullptr),
+                                 d_msg_off ? d_msg_off + lo : nullptr, msg_stride, msg_len, cnt,
+                                 d_coeffs ? d_coeffs + (size_t)coeff_bytes * lo : nullptr, coeff_bytes, nullptr,
+                                 recs + 24 * j, d_h ? d_h + 4 * lo : nullptr))
+            return rc;
+    }
+    return msm_combine_records(ctx, recs, k, d_verdict_out, d_partial_out);
+}
+
+// the kernels of one MSM-form slice on ctx->stream: a verdict (d_partial_out == nullptr) or the slice's / shard's record
+// d_h: the challenge scalars if they exist already, else nullptr (they are computed into ctx->ws_h)
+static int msm_run_one(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                       const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                       const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out,
+                       const u64 *d_h) {
+    if (n > (1ull << 25)) return SSA_ERR_ARG;   // 2n * 16 sort items must fit the sort's 32-bit positions
     if (n == 0) {   // empty batch: Ok (src/batch.rs); an empty shard adds the identity and 0
         if (d_partial_out) {
-            HIP_TRY(hipMemsetAsync(d_partial_out, 0, 24 * sizeof(u64), ctx->stream));
+            hipLaunchKernelGGL(msm_k_empty_record, dim3(1), dim3(64), 0, ctx->stream, d_partial_out);
+            HIP_TRY(hipGetLastError());
             return 0;
         }
         HIP_TRY(hipMemsetAsync(d_verdict_out, 0, sizeof(uint32_t), ctx->stream));
@@ -763,7 +806,7 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
     if (ctx->msm_cnt.reserve(nb * 4) || ctx->msm_cnt2.reserve(nb * 4) || ctx->msm_ids.reserve(nb * 4) ||
         ctx->msm_ids2.reserve(nb * 4))
         return SSA_ERR_HIP;
-    if (ctx->ws_h.reserve(n * 32) || ctx->msm_points.reserve(npts * 96) || ctx->msm_scalars.reserve(npts * 32) ||
+    if ((!d_h && ctx->ws_h.reserve(n * 32)) || ctx->msm_points.reserve(npts * 96) || ctx->msm_scalars.reserve(npts * 32) ||
         ctx->msm_keys.reserve(total * 4) || ctx->msm_vals.reserve(total * 4) || ctx->msm_keys2.reserve(total * 4) ||
         ctx->msm_vals2.reserve(total * 4) || ctx->msm_sort_tmp.reserve(sort_tmp + 16) ||
         ctx->msm_bounds.reserve(nb * 8) || ctx->msm_buckets.reserve(nb * 144) ||
@@ -774,11 +817,13 @@ static int msm_run(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, co
     HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->msm_bounds.p, 0, nb * 8, ctx->stream));
     // challenge scalars h_i with the kernel of the per-lane path
-    if (!hashed)
+    if (!d_h) {
         if (int rc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+        d_h = (const u64 *)ctx->ws_h.p;
+    }
     int rc = timed_launch(ctx, "msm_k_prepare", [&] {
         hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, ctx->stream, d_sigs, d_pks, d_pk_inf,
-                           (const u64 *)ctx->ws_h.p, d_coeffs, coeff_bytes, n, (u64 *)ctx->msm_points.p,
+                           d_h, d_coeffs, coeff_bytes, n, (u64 *)ctx->msm_points.p,
                            (u64 *)ctx->msm_scalars.p, (u64 *)ctx->msm_partials.p, (u32 *)ctx->msm_flags.p);
     });
     if (rc) return rc;
@@ -836,7 +881,10 @@ extern "C" int ssa_verify_batch_msm_partial(ssa_ctx *ctx, const uint8_t *sigs, c
     if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     std::memset(out24, 0, SSA_MSM_PARTIAL_WORDS * sizeof(uint64_t));
-    if (n == 0) return 0;
+    if (n == 0) {
+        out24[23] = SSA_MSM_RECORD_MAGIC;    // the empty shard's record: identity, 0
+        return 0;
+    }
     StagedInputs s;
     const void *p;
     if (int rc = stage_up(ctx, ctx->st_sigs, sigs, n * 81, &p)) return rc;
@@ -882,15 +930,55 @@ __global__ void msm_k_unpack_parts(const u64 *__restrict__ parts, u32 k, u64 *__
     if (t >= k * 24u) return;
     const u32 j = t / 24u, w = t % 24u;
     const u64 v = parts[t];
-    if (w < 18) pts[18u * j + w] = v;
-    else if (w < 22) lins[4u * j + (w - 18u)] = v;
-    else if (w == 22 && v != 0) atomicOr(malformed, 1u);
+    if (w < 18) {
+        pts[18u * j + w] = v;
+        if (v >= FP_P) atomicOr(malformed, 1u);                 // limbs of a record are canonical
+    } else if (w < 22) {
+        lins[4u * j + (w - 18u)] = v;
+    } else if (w == 22) {
+        if (v != 0) atomicOr(malformed, 1u);
+    } else if (v != SSA_MSM_RECORD_MAGIC) {
+        atomicOr(malformed, 1u);   // not a record of this format: never written (all zero), foreign version, garbled
+    }
+}
+
+// One lane per record: the scalar is canonical (< q) and the point is the identity (Z = 0) or satisfies the Jacobian
+// curve equation Y^2 = X^3 + X Z^4 + (u + 395) Z^6.  Records cross process boundaries (all-gather): a corrupted or
+// foreign one gives SSA_MALFORMED, never an arbitrary verdict.  k <= 4096: the cost is one short launch.
+__global__ void __launch_bounds__(64)
+msm_k_check_parts(const u64 *__restrict__ parts, u32 k, u32 *__restrict__ malformed) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const u64 *r = parts + 24u * (size_t)j;
+    bool ok = true;
+    fp6 X, Y, Z;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        X.c[c] = r[c];
+        Y.c[c] = r[6 + c];
+        Z.c[c] = r[12 + c];
+        ok = ok && X.c[c] < FP_P && Y.c[c] < FP_P && Z.c[c] < FP_P;
+    }
+    sc256 lin;
+#pragma unroll
+    for (int c = 0; c < 4; c++) lin.w[c] = r[18 + c];
+    ok = ok && !sc_geq_q(lin);
+    if (ok && !f6_is_zero(Z)) {
+        const fp6 z2 = f6_sqr(Z), z4 = f6_sqr(z2), z6 = f6_mul(z4, z2);
+        fp6 b = f6_zero();
+        b.c[0] = 395ull;
+        b.c[1] = 1ull;
+        const fp6 rhs = f6_add(f6_add(f6_mul(f6_sqr(X), X), f6_mul(X, z4)), f6_mul(b, z6));
+        ok = f6_eq(f6_sqr(Y), rhs);
+    }
+    if (!ok) atomicOr(malformed, 1u);
 }
 }  // namespace ssa
 
 // The shards added up on one device: one Jacobian addition per shard, the scalars mod q, [lin]G from the comb table and
 // the x-only comparison (src/batch.rs:98-100,123-129) -- msm_k_finish with no doublings between its "windows".
-static int msm_combine_records(ssa_ctx *ctx, const u64 *d_records, size_t k, uint32_t *d_verdict_out, u64 *d_partial_out) {
+static int msm_combine_records(ssa_ctx *ctx, const u64 *d_records, size_t k, uint32_t *d_verdict_out, u64 *d_partial_out,
+                               bool check_points) {
     if (ctx->msm_comb_pts.reserve(18 * k * sizeof(u64)) || ctx->msm_comb_lins.reserve(4 * k * sizeof(u64)) ||
         ctx->msm_flags.reserve(64))
         return SSA_ERR_HIP;
@@ -898,6 +986,11 @@ static int msm_combine_records(ssa_ctx *ctx, const u64 *d_records, size_t k, uin
     hipLaunchKernelGGL(msm_k_unpack_parts, dim3(grid_for(k * 24, 256)), dim3(256), 0, ctx->stream, d_records, (u32)k,
                        (u64 *)ctx->msm_comb_pts.p, (u64 *)ctx->msm_comb_lins.p, (u32 *)ctx->msm_flags.p);
     HIP_TRY(hipGetLastError());
+    if (check_points) {
+        hipLaunchKernelGGL(msm_k_check_parts, dim3(grid_for(k, 64)), dim3(64), 0, ctx->stream, d_records, (u32)k,
+                           (u32 *)ctx->msm_flags.p);
+        HIP_TRY(hipGetLastError());
+    }
     MsmShape sh;
     sh.c = 0;
     sh.windows = (u32)k;
@@ -913,7 +1006,7 @@ static int msm_combine_records(ssa_ctx *ctx, const u64 *d_records, size_t k, uin
 extern "C" int ssa_msm_combine_device(ssa_ctx *ctx, const uint64_t *d_parts24, size_t k, uint32_t *d_verdict_out) {
     if (!ctx || !d_parts24 || !d_verdict_out || k == 0 || k > 4096) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    return msm_combine_records(ctx, (const u64 *)d_parts24, k, d_verdict_out, nullptr);
+    return msm_combine_records(ctx, (const u64 *)d_parts24, k, d_verdict_out, nullptr, true);
 }
 
 extern "C" int ssa_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k) {

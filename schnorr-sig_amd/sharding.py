@@ -104,10 +104,26 @@ def gather_msm_partials(local_record, world, dist):
     return out.reshape(world, MSM_PARTIAL_WORDS)
 
 
-def msm_verdict(local_record, world, dist, combine):
+def msm_verdict(local_record, world, dist, combine, engine=None):
     """verify_batch's single verdict for a batch sharded over `world` ranks in the MSM form: gather the shard records,
     then `combine(records)` -- ssa_msm_combine[_device] on this rank's context: one point addition per shard, [sum]G,
     x-only compare -- on EVERY rank (each holds all the records, so no broadcast of the verdict is needed and the ranks
-    cannot disagree: the combination is deterministic).  Returns (verdict, records)."""
+    cannot disagree: the combination is deterministic).  Returns (verdict, records).
+
+    ORDERING.  ssa_verify_batch_msm_partial_device only ENQUEUES the record on the engine's stream, and the gather
+    runs on torch's current stream: pass `engine` (the Engine that produced `local_record`) and the two are ordered
+    here -- torch's stream waits for the engine before the gather (ssa_ctx_stream_release), the engine's stream waits
+    for the gather before `combine` (ssa_ctx_stream_acquire), no host synchronisation.  With engine=None the caller
+    vouches that the record is complete (Engine.sync(), or one shared stream through Engine.set_stream).  A record the
+    kernel has not written yet is NOT mistaken for an empty shard: every record carries a magic word and the
+    combination returns MALFORMED without it (include/schnorr_sig_amd.h)."""
+    on_device = engine is not None and getattr(local_record, "is_cuda", False)
+    if on_device:
+        import torch
+        engine.stream_release(torch.cuda.current_stream(local_record.device).cuda_stream)
+    elif engine is not None:
+        engine.sync()
     records = gather_msm_partials(local_record, world, dist)
+    if on_device:
+        engine.stream_acquire(torch.cuda.current_stream(local_record.device).cuda_stream)
     return combine(records), records

@@ -5,6 +5,32 @@ import numpy as np
 
 P = 2**64 - 2**32 + 1
 Q = 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
+MAGIC = 0x5353415245430004      # SSA_MSM_RECORD_MAGIC (include/schnorr_sig_amd.h): word 23 of every record
+
+
+def empty_record():
+    """the record of an empty shard: the identity, 0, not malformed -- and the magic word"""
+    r = np.zeros(24, np.uint64)
+    r[23] = MAGIC
+    return r
+
+
+def record_is_wellformed(orc, rec):
+    """what ssa_msm_combine checks before it trusts a record: the magic word, canonical limbs and scalar, flag in
+    {0, 1}, and the point is the identity (Z = 0) or on the curve (Jacobian: Y^2 = X^3 + X Z^4 + (u + 395) Z^6)"""
+    if int(rec[23]) != MAGIC or int(rec[22]) > 1:
+        return False
+    if any(int(v) >= P for v in rec[:18]) or record_lin(rec) >= Q:
+        return False
+    X, Y, Z = (tuple(int(v) for v in rec[6 * k:6 * k + 6]) for k in range(3))
+    if not any(Z):
+        return True
+    z2 = _f6_mul(orc, Z, Z)
+    z4 = _f6_mul(orc, z2, z2)
+    z6 = _f6_mul(orc, z4, z2)
+    rhs = [(a + b + c) % P for a, b, c in zip(_f6_mul(orc, _f6_mul(orc, X, X), X), _f6_mul(orc, X, z4),
+                                               _f6_mul(orc, (395, 1, 0, 0, 0, 0), z6))]
+    return tuple(rhs) == _f6_mul(orc, Y, Y)
 
 
 def _neg(pt):
@@ -58,7 +84,7 @@ def cpu_combine(orc, records):
     """ssa_msm_combine on the CPU: 3 if any record is flagged malformed, else compare the x coordinates of the sum of
     the shard points and of [sum lin]G (src/batch.rs:98-100, :123-129; the identity's x is taken as 0)"""
     records = np.asarray(records, dtype=np.uint64).reshape(-1, 24)
-    if any(int(r[22]) for r in records):
+    if any(int(r[22]) for r in records) or not all(record_is_wellformed(orc, r) for r in records):
         return 3
     left, lin = None, 0
     for r in records:

@@ -144,8 +144,12 @@ def test_msm_partial_and_combine_public_api(engine, oracle, n):
         tam = rec.copy()
         tam[0, :18], tam[1, :18] = rec[1, :18], rec[0, :18]                    # points swapped, scalars not: still the same sums
         assert engines[2].msm_combine(tam) == 0
-        tam[0, 0] ^= np.uint64(2)
-        assert engines[2].msm_combine(tam) == 2
+        tam[0, 0] ^= np.uint64(2)                                               # a point off the curve is not a record:
+        assert engines[2].msm_combine(tam) == 3                                 # the combination fails closed (round 4)
+        for w, v in ((23, 0), (23, ssa.MSM_RECORD_MAGIC ^ 1), (5, 2**64 - 1), (21, 2**63), (22, 2)):
+            tam = rec.copy()
+            tam[1, w] = np.uint64(v)                                            # no magic / foreign format / limb >= p / scalar >= q / bad flag
+            assert engines[2].msm_combine(tam) == 3, (w, v)
         # one corrupted signature in the last shard
         bad = sigs.copy()
         bad[n - 1, 50] ^= 4
@@ -170,11 +174,23 @@ def test_msm_partial_and_combine_public_api(engine, oracle, n):
             e.close()
 
 
+def ssa_magic():
+    import schnorr_sig_amd as ssa
+    return np.uint64(ssa.MSM_RECORD_MAGIC)
+
+
 def test_msm_combine_rejects_bad_arguments(engine):
     with pytest.raises(RuntimeError, match="invalid argument"):
         engine.msm_combine(np.zeros((0, 24), np.uint64))
     # k empty shards: the identity on the left, [0]G on the right -> Ok, like the reference's empty batch
-    assert engine.msm_combine(np.zeros((2, 24), np.uint64)) == 0
+    empty = np.zeros((2, 24), np.uint64)
+    empty[:, 23] = ssa_magic()
+    assert engine.msm_combine(empty) == 0
+    assert (engine.verify_batch_msm_partial(np.zeros((0, 81), np.uint8), np.zeros((0, 96), np.uint8), None) == empty[0]).all()
+    # a slot nobody wrote is NOT an empty shard (an unwritten torch.zeros(24) must not read as "accept")
+    assert engine.msm_combine(np.zeros((2, 24), np.uint64)) == 3
+    empty[1, 23] = 0
+    assert engine.msm_combine(empty) == 3
 
 
 def test_sharding_msm_verdict_single_process(engine):
@@ -220,22 +236,23 @@ def test_async_device_verify_followed_by_pipelined_host_verify(engine, oracle):
 
 
 def test_pipelined_upload_error_paths(engine, oracle):
-    """An error after the first enqueue of the chunked upload (injected: SSA_FAULT_AFTER_CHUNK) must return an error
+    """An error after the first enqueue of the chunked upload (injected: ssa_debug_fault_after_chunk) must return an error
     code with every stream drained -- the caller's arrays are unpinned and may be freed at once -- and the next call on
     the context must be correct.  Bad message arguments are refused before anything is pinned or enqueued."""
     rng = np.random.default_rng(3300)
     n = (1 << 17) + 5
     sigs, pks, msgs = honest(engine, rng, n)
     sigs[7, 49] ^= 1
-    for chunk in ("0", "3", "7"):
-        os.environ["SSA_FAULT_AFTER_CHUNK"] = chunk
+    for chunk in (0, 3, 7):
         try:
+            engine.debug_fault_after_chunk(chunk)          # one shot: armed before each call
             with pytest.raises(RuntimeError, match="HIP runtime error"):
                 engine.verify_many(sigs, pks, msgs, check_torsion=False, mode="lane")
+            engine.debug_fault_after_chunk(chunk)
             with pytest.raises(RuntimeError, match="HIP runtime error"):
                 engine.verify_batch_msm(sigs, pks, msgs, coeffs=coeffs32(rng, n))
         finally:
-            del os.environ["SSA_FAULT_AFTER_CHUNK"]
+            engine.debug_fault_after_chunk(-1)
         # the arrays the failed call read are released and overwritten right away
         scratch = sigs.copy()
         scratch[:] = 0

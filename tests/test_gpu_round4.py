@@ -1,0 +1,264 @@
+"""GPU tests added in round 4 (all through the C ABI):
+ * bench.py with TWO ranks on real kernels (gloo rendezvous, both ranks on the one GPU of the box): every rank != 0
+   branch of the N > 1 run -- the receive side of the scatter / broadcast, the ragged config-4 shard, the all-reduced
+   rejection counts, the MSM records of two shards gathered and combined -- before the driver's multi-GPU node sees it
+   (BASELINE.json configs[3], SURVEY.md 8(e), reference src/batch.rs:98-129);
+ * the headline's flags (SSA_FLAG_SIG_FLAG_BYTE = what ssa_verify_batch runs, src/batch.rs:104) in the bench line."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q = 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
+
+
+def make_scalars(rng, n):
+    s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    s[:, 31] &= 0x3F
+    s[:, 0] |= 1
+    return s
+
+
+def honest(engine, rng, n, msg_len=80):
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, msg_len), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    return sigs, pks, msgs
+
+
+def _bench(args, env_extra=None, timeout=900):
+    """bench.py as a FRESH child process (never an exec of this process, which has touched the GPU)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT",
+                                                            "MASTER_ADDR", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+# ---------------------------------------------------------------- N = 2 with real kernels
+def test_bench_two_ranks_real_kernels_corrupted_and_ragged():
+    """Two ranks (gloo: the box has one GPU, both ranks run their kernels on it), 1 % corrupted shards, a config-4 leg
+    whose total does not divide by two (rank 1 gets the short shard), MSM records of both shards combined."""
+    out = _bench(["--gpus", "2", "--batch", "65536", "--strong-total", "262145", "--corrupt", "0.01", "--steps", "2",
+                  "--warmup", "1"], env_extra={"SSA_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["config"]["backend"] == "gloo"
+    assert len(out["ranks"]) == 2 and sorted(r[0] for r in out["ranks"]) == [0, 1]
+    assert out["config"]["signatures_per_gpu"] == 65536 and out["config"]["signatures_total"] == 131072
+    assert out["scaling"] == "weak"
+    # the all-reduced rejection count: both shards' 655 corruptions
+    assert out["rejected"] == 2 * 655 and out["all_verdicts_as_expected"] is True
+    assert out["with_torsion_check_rejected"] == 2 * 655
+    assert out["value"] > 0 and abs(out["value"] - 131072 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    # flags of the timed step = what ssa_verify_batch runs
+    assert out["config"]["flags"]["word"] == 8
+    # config-4 leg: ONE ragged batch on rank 0 -> scatter and broadcast both timed, honest batch
+    c4 = out["config4_strong"]
+    assert "error" not in c4, c4
+    assert c4["signatures_total"] == 262145 and c4["rejected"] == 0
+    assert c4["scatter_ms"] is not None and c4["scatter_ms"] > 0
+    assert c4["broadcast_ms"] is not None and c4["broadcast_ms"] > 0
+    # MSM form: one verdict over both ranks' records (k = 2)
+    msm = out["verify_batch_msm_form"]
+    assert msm["combined_over_ranks"] is True and msm["verdict"] == msm["expected_verdict"] == 2
+    # the CPU leg belongs to the N = 1 line
+    assert out["cpu_baseline"] is None and "N = 1" in out["cpu_baseline_note"]
+    assert out["parity_unpinned"] is True
+
+
+def test_bench_two_ranks_honest_msm_verdict_is_ok():
+    out = _bench(["--gpus", "2", "--batch", "16384", "--steps", "1", "--warmup", "1", "--no-strong-leg"],
+                 env_extra={"SSA_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["rejected"] == 0 and out["all_verdicts_as_expected"] is True
+    msm = out["verify_batch_msm_form"]
+    assert msm["combined_over_ranks"] is True and msm["verdict"] == msm["expected_verdict"] == 0
+    assert out["config4_strong"] is None
+
+
+def test_bench_strong_mode_two_ranks_ragged_total():
+    """`--total` (config 4 as the main mode): rank 0 generates, both distributions run, rank 1's shard is one short"""
+    out = _bench(["--gpus", "2", "--total", "100001", "--steps", "1", "--warmup", "1", "--skip-torsion-leg"],
+                 env_extra={"SSA_BENCH_BACKEND": "gloo"})
+    assert out["scaling"] == "strong" and out["config"]["signatures_total"] == 100001
+    assert out["config"]["signatures_per_gpu"] == 50001          # rank 0's shard (earlier ranks take the remainder)
+    assert out["scatter_ms"] > 0 and out["broadcast_ms"] > 0
+    assert out["rejected"] == 0 and out["all_verdicts_as_expected"] is True
+
+
+def test_bench_line_names_its_flags_and_cpu_leg_runs_them():
+    out = _bench(["--gpus", "1", "--batch", "8192", "--steps", "1", "--warmup", "1", "--skip-torsion-leg",
+                  "--cpu-sample", "512", "--corrupt", "0.01"])
+    assert out["config"]["flags"] == {"word": 8, "names": ["SSA_FLAG_SIG_FLAG_BYTE"],
+                                     "meaning": out["config"]["flags"]["meaning"]}
+    assert "verify_batch semantics" in out["config"]["workload"]
+    cb = out["cpu_baseline"]
+    assert cb["flags"] == 8 and cb["agrees_with_gpu"] is True and "SSA_FLAG_SIG_FLAG_BYTE" in cb["sample"]
+
+
+# ---------------------------------------------------------------- bounded workspaces: slices of a fixed lane count
+def _sliced_engine(lane=65536, msm=65536):
+    """an engine whose per-lane kernels / MSM pipeline run over slices of the given size (read at ssa_ctx_create)"""
+    import schnorr_sig_amd as ssa
+    os.environ["SSA_LANE_SLICE"], os.environ["SSA_MSM_SLICE"] = str(lane), str(msm)
+    try:
+        return ssa.Engine(0)
+    finally:
+        del os.environ["SSA_LANE_SLICE"], os.environ["SSA_MSM_SLICE"]
+
+
+def _spoil(rng, sigs, pks, msgs, count):
+    """config-5 style corruptions on `count` distinct lanes; returns (sigs, pks, msgs, pk_inf, bad indices)"""
+    n = sigs.shape[0]
+    sigs, pks, msgs = sigs.copy(), pks.copy(), msgs.copy()
+    bad = rng.permutation(n)[:count]
+    q = count // 4
+    sigs[bad[:q], 49] ^= 1                                  # e bit flip
+    msgs[bad[q:2 * q], 17] ^= 0x20                          # message bit flip
+    pks[bad[2 * q:3 * q]] = pks[(bad[2 * q:3 * q] + 1) % n]  # someone else's key
+    sigs[bad[3 * q:], :49] = sigs[(bad[3 * q:] + 1) % n, :49]  # someone else's R
+    inf = np.zeros(n, np.uint8)
+    inf[bad[0]] = 1                                         # an identity key on a lane that is rejected anyway
+    return sigs, pks, msgs, inf, bad
+
+
+def test_lane_kernels_in_slices_equal_the_unsliced_run(engine, oracle):
+    """ws_tab is sized for one slice whatever n is (SSA_MAX_BATCH is honest): slice forced to 65 536 lanes at a ragged
+    n = 200 001 -- same status vector and ONE rejection count as the unsliced engine, device and host-buffer (pipelined)
+    entry points, subgroup check on and off, flag-byte semantics on and off; oracle on a sample and every spoiled lane"""
+    import torch
+    rng = np.random.default_rng(4100)
+    n = 200001
+    sigs, pks, msgs = honest(engine, rng, n)
+    sigs, pks, msgs, inf, bad = _spoil(rng, sigs, pks, msgs, 400)
+    eng2 = _sliced_engine()
+    dev = torch.device("cuda", 0)
+    try:
+        ds, dp, dm, di = (torch.from_numpy(a).to(dev) for a in (sigs, pks, msgs, inf))
+        samp = np.unique(np.concatenate([bad, np.arange(0, n, 197), [65535, 65536, 131071, 131072, 196607, 196608, n - 1]]))
+        for torsion in (False, True):
+            for fb in (False, True):
+                ref, nf_ref = engine.verify_many(sigs, pks, msgs, check_torsion=torsion, pk_inf=inf, mode="lane",
+                                                 sig_flag_byte=fb)
+                got, nf = eng2.verify_many(sigs, pks, msgs, check_torsion=torsion, pk_inf=inf, mode="lane",
+                                           sig_flag_byte=fb)                   # n >= 2^17: pipelined upload + slices
+                assert nf == nf_ref == int((ref != 0).sum()) and (got == ref).all()
+                dst = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+                dnf = torch.zeros(1, dtype=torch.int64, device=dev)
+                eng2.verify_many_device(ds.data_ptr(), dp.data_ptr(), dm.data_ptr(), n, 80, dst.data_ptr(), dnf.data_ptr(),
+                                        d_pk_inf=di.data_ptr(), check_torsion=torsion, mode="lane", sig_flag_byte=fb)
+                eng2.sync()
+                assert int(dnf.item()) == nf_ref and (dst.cpu().numpy() == ref).all()
+                exp = oracle.verify_many(sigs[samp], pks[samp], msgs[samp], check_torsion=torsion, pk_inf=inf[samp],
+                                         sig_flag_byte=fb)
+                assert (ref[samp] == exp).all()
+            assert nf_ref == 400
+        # ragged messages through the offset table (the slices move the table, not the bytes)
+        lens = rng.integers(0, 30, size=n)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum(lens)
+        flat = rng.integers(0, 256, size=int(off[-1]) + 1, dtype=np.uint8)
+        m2 = 70001
+        sk, nn = make_scalars(rng, m2), make_scalars(rng, m2)
+        pk2, sg2 = engine.keygen_sign_many(sk, nn, flat, offsets=off[:m2 + 1])
+        sg2[5, 60] ^= 2
+        sg2[66000, 49] ^= 1
+        ref, nf_ref = engine.verify_many(sg2, pk2, flat, offsets=off[:m2 + 1], check_torsion=False, mode="lane")
+        got, nf = eng2.verify_many(sg2, pk2, flat, offsets=off[:m2 + 1], check_torsion=False, mode="lane")
+        assert nf == nf_ref == 2 and (got == ref).all() and got[5] == 2 and got[66000] == 2
+        # the other kernel family (one block per signature, no per-lane workspace) on the same engine
+        sub = slice(0, 70001)
+        ref_c, _ = engine.verify_many(sigs[sub], pks[sub], msgs[sub], check_torsion=True, pk_inf=inf[sub], mode="lane")
+        got_c, _ = eng2.verify_many(sigs[sub], pks[sub], msgs[sub], check_torsion=True, pk_inf=inf[sub], mode="coop")
+        assert (got_c == ref_c).all()
+    finally:
+        eng2.close()
+
+
+@pytest.mark.parametrize("n", [200001, 3 * 65536 + 100])
+def test_msm_form_in_slices_equals_the_unsliced_verdict(engine, oracle, n):
+    """more than msm_slice signatures: every slice is reduced to its record like a shard of a multi-GPU batch and the
+    records are combined (src/batch.rs:98-129); forced to 65 536 here -- the last slice is ragged (3 393 signatures) or
+    small enough for the cooperative small-batch path (100)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import msm_records as mr
+    rng = np.random.default_rng(4200 + n % 1000)
+    sigs, pks, msgs = honest(engine, rng, n)
+    co = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    co[:, 16:] = 0
+    eng2 = _sliced_engine()
+    try:
+        assert engine.verify_batch_msm(sigs, pks, msgs, coeffs=co) == eng2.verify_batch_msm(sigs, pks, msgs, coeffs=co) == 0
+        assert eng2.verify_batch_msm(sigs, pks, msgs) == 0                           # library-drawn coefficients per slice
+        # the record of the whole batch: same affine point and scalar whichever way it was cut
+        r1 = engine.verify_batch_msm_partial(sigs, pks, msgs, coeffs=co)
+        r2 = eng2.verify_batch_msm_partial(sigs, pks, msgs, coeffs=co)
+        assert mr.record_point(oracle, r1) == mr.record_point(oracle, r2) and mr.record_lin(r1) == mr.record_lin(r2)
+        assert int(r2[23]) == mr.MAGIC and mr.record_is_wellformed(oracle, r2)
+        for lane in (7, 65536, n - 1):                                               # one bad signature in the first / a middle / the last slice
+            bad = sigs.copy()
+            bad[lane, 52] ^= 0x40
+            assert eng2.verify_batch_msm(bad, pks, msgs, coeffs=co) == 2
+        und = sigs.copy()
+        und[n - 2, 48] |= 4                                                         # undecodable flag byte: the reference panics
+        assert eng2.verify_batch_msm(und, pks, msgs, coeffs=co) == engine.verify_batch_msm(und, pks, msgs, coeffs=co) == 3
+        inf = np.zeros(n, np.uint8)
+        inf[70000] = 1
+        assert eng2.verify_batch_msm(sigs, pks, msgs, coeffs=co, pk_inf=inf) == 2
+    finally:
+        eng2.close()
+
+
+# ---------------------------------------------------------------- stream ordering of the shard records
+def test_msm_partial_on_its_own_stream_is_ordered_by_msm_verdict():
+    """ssa_verify_batch_msm_partial_device only enqueues on the context's stream -- here the context's OWN non-blocking
+    stream, never handed to torch -- while the gather runs on torch's current stream.  sharding.msm_verdict(engine=...)
+    orders the two without a host synchronisation; alternating honest and forged batches into the SAME record buffer
+    would show a stale or unwritten record as a wrong verdict."""
+    import torch
+    import schnorr_sig_amd as ssa
+    from schnorr_sig_amd.sharding import msm_verdict
+    eng = ssa.Engine(0)
+    try:
+        rng = np.random.default_rng(4300)
+        n = 20000
+        sigs, pks, msgs = honest(eng, rng, n)
+        bad = sigs.copy()
+        bad[n // 2, 49] ^= 1
+        dev = torch.device("cuda", 0)
+        d_good, d_bad, dp, dm = (torch.from_numpy(a).to(dev) for a in (sigs, bad, pks, msgs))
+        record = torch.zeros(24, dtype=torch.int64, device=dev)
+        verdict = torch.full((1,), 255, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def combine(records):
+            eng.msm_combine_device(records.data_ptr(), records.shape[0], verdict.data_ptr())
+            return verdict
+
+        side = torch.cuda.Stream(device=dev)
+        for it in range(8):
+            ds = d_good if it % 2 == 0 else d_bad
+            eng.verify_batch_msm_partial_device(ds.data_ptr(), dp.data_ptr(), dm.data_ptr(), n, 80, 0, 16,
+                                                record.data_ptr())
+            with torch.cuda.stream(side if it >= 4 else torch.cuda.current_stream()):
+                _, recs = msm_verdict(record, 1, None, combine, engine=eng)      # no host synchronisation in here
+            eng.sync()
+            assert int(verdict.cpu().item()) == (0 if it % 2 == 0 else 2), it
+            assert int(recs.cpu()[0, 23]) == ssa.MSM_RECORD_MAGIC - (1 << 64 if ssa.MSM_RECORD_MAGIC >= 1 << 63 else 0)
+        # a record buffer nobody wrote is not an empty shard
+        blank = torch.zeros((1, 24), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        combine(blank)
+        eng.sync()
+        assert int(verdict.cpu().item()) == 3
+    finally:
+        eng.close()
