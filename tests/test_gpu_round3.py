@@ -126,7 +126,7 @@ def test_msm_partial_and_combine_public_api(engine, oracle, n):
     try:
         # honest
         rec = records_host(sigs)
-        assert (rec[:, 22:] == 0).all()
+        assert (rec[:, 22] == 0).all() and (rec[:, 23] == np.uint64(ssa.MSM_RECORD_MAGIC)).all()
         assert engines[1].msm_combine(rec) == engine.verify_batch_msm(sigs, pks, msgs, coeffs=co) == 0
         rec_d = records_device(sigs)
         assert (rec_d.cpu().numpy().astype(np.uint64) == rec).all(), "device and host records differ"
