@@ -20,6 +20,9 @@
  *                                                           src/public.rs:54-56, src/batch.rs:104
  *   ssa_keygen_sign_many    <- KeyPair::new / KeyPair::sign src/keypair.rs:57-65,
  *                                                           src/signature.rs:114-129
+ *   ssa_keygen_sign_many_ex <- the same, constant-time (SSA_FLAG_SIGN_CT) and / or as KeyedSignature records
+ *                              (sign_and_bind_pkey + KeyedSignature::to_bytes, src/signature.rs:132-156,237-245)
+ *   ssa_compress_many       <- PublicKey::to_bytes          src/public.rs:49-51
  *   status codes            <- SignatureError               src/error.rs:13-18
  *   record sizes            <- src/constants.rs:12-30
  *
@@ -68,7 +71,8 @@ extern "C" {
 #define SSA_ERR_NO_DEVICE (-4)
 
 /* flags */
-#define SSA_MAX_BATCH ((size_t)1 << 30)   /* signatures per call; larger n returns SSA_ERR_ARG */
+#define SSA_MAX_BATCH ((size_t)1 << 30)   /* signatures per call; larger n returns SSA_ERR_ARG.  The per-lane workspaces are
+                                             sized for slices of 2^20 lanes (2.1 GB; SSA_LANE_SLICE), not for n */
 #define SSA_FLAG_FORCE_LANE 2u    /* always the throughput kernels (one signature per lane) */
 #define SSA_FLAG_FORCE_COOP 4u    /* always the low-latency kernel (one wave per signature) */
 #define SSA_FLAG_CHECK_TORSION 1u /* Signature::verify semantics (src/signature.rs:182-184);
@@ -146,7 +150,8 @@ int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, cons
  * NULL for 128-bit coefficients from a ChaCha20 stream (RFC 8439) generated on the device and keyed per
  * call with getrandom(2).  Returns SSA_OK, SSA_INVALID_SIGNATURE, or
  * SSA_MALFORMED where the reference panics (undecodable sig.x, src/batch.rs:67,104).  No torsion
- * check, like the reference.  n <= 2^25 per call. */
+ * check, like the reference.  Any n <= SSA_MAX_BATCH: above 2^24 signatures (SSA_MSM_SLICE) the batch runs slice after slice,
+ * each reduced to its record like a shard, the records added up (src/batch.rs:98-129) -- bounded device memory. */
 int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
                          size_t n, const uint8_t *coeffs);
@@ -171,6 +176,32 @@ int ssa_rescue_hash_many(ssa_ctx *ctx, const uint64_t *felts, uint32_t felts_per
 int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces,
                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
                          size_t msg_len, size_t n, uint8_t *pks_out, uint8_t *sigs_out);
+
+/* The signing side with options (KeyPair::sign / sign_and_bind_pkey, src/signature.rs:114-156; PrivateKey::sign,
+ * :65-110).  flags:
+ *   SSA_FLAG_SIGN_CT     constant-time in the secrets, like the reference's `&BASEPOINT_TABLE * r` and Scalar::from_bits
+ *                        (src/signature.rs:67,116,123): fixed 4-bit windows over a 98 KB table that is read in full for
+ *                        every window (the entry is selected, never indexed), no skipped window, generic additions from a
+ *                        public offset point with no exceptional-case branch, masked scalar arithmetic, compiled (branch-
+ *                        free) field blocks.  Same bytes out as the throughput signer; about 5x its time.  A lane whose
+ *                        addition meets an exceptional input (probability ~2^-250; surely only for a scalar that reduces
+ *                        to 0, which the host form refuses) is recomputed by the exact variable-time code.
+ *   SSA_FLAG_SIGN_KEYED  sigs_out receives n x 130-byte KeyedSignature records pk(49, compressed) || sig(81)
+ *                        (KeyedSignature::to_bytes, src/signature.rs:237-245) instead of n x 81 bytes; pks_out may be
+ *                        NULL then.
+ * The host form checks the scalars (canonical, non-zero: SSA_ERR_ARG otherwise) in time independent of their values
+ * and wipes its device copies of them before it returns.  ssa_keygen_sign_many[_device] = flags 0. */
+#define SSA_FLAG_SIGN_CT 16u
+#define SSA_FLAG_SIGN_KEYED 32u
+int ssa_keygen_sign_many_ex(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces, const uint8_t *msgs,
+                            const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n, uint32_t flags,
+                            uint8_t *pks_out, uint8_t *sigs_out);
+
+/* PublicKey::to_bytes (AffinePoint::to_compressed, src/public.rs:49-51): n x 96-byte affine points -> n x 49 bytes
+ * x || flag byte (bit 7: the identity, [0; 48] || 0x80, src/public.rs:95-101 -- marked by pk_inf[i] != 0, optional; bit 6:
+ * the sort flag of y).  status_out (optional): 0, or SSA_MALFORMED for a limb that is not canonical. */
+int ssa_compress_many(ssa_ctx *ctx, const uint8_t *pks, const uint8_t *pk_inf, size_t n, uint8_t *out,
+                      uint8_t *status_out);
 
 #define SSA_KEYED_SIGNATURE_LENGTH 130  /* src/constants.rs:30 */
 /* n x KeyedSignature::verify on the 130-byte wire form pk(49, compressed) || sig(81)
@@ -205,6 +236,12 @@ int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_
                                 uint8_t *d_sigs_out);
 int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t n, uint8_t *d_pks_out,
                                uint8_t *d_pk_inf_out, uint8_t *d_status_out);
+/* (cannot report errors per lane: scalars are reduced mod q; d_pks_out may be NULL with SSA_FLAG_SIGN_KEYED) */
+int ssa_keygen_sign_many_ex_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces, const uint8_t *d_msgs,
+                                   const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                                   uint32_t flags, uint8_t *d_pks_out, uint8_t *d_sigs_out);
+int ssa_compress_many_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t n, uint8_t *d_out,
+                             uint8_t *d_status_out);
 /* coeff_bytes in 1..32: little-endian coefficient width (d_coeffs == NULL: the library draws 128-bit
  * coefficients as above); *d_verdict_out receives the status */
 int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,

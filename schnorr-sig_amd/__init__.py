@@ -7,7 +7,9 @@ to it.  There is no CPU compute path; if the HIP library is missing, import fail
 Reference API mirrored (names and semantics, reference file:line):
   Signature.verify(message, pkey)            src/signature.rs:181-205
   PublicKey.verify_signature / KeyPair.verify_signature   src/signature.rs:159-176
-  KeyPair.new / KeyPair.sign                 src/keypair.rs:57-65, src/signature.rs:114-129
+  KeyPair.new / KeyPair.sign / sign_and_bind_pkey   src/keypair.rs:57-65, src/signature.rs:114-156
+  PublicKey.to_bytes / from_bytes            src/public.rs:49-56
+  KeyedSignature.to_bytes / from_bytes       src/signature.rs:236-271
   verify_batch(signatures, public_keys, messages, rng)    src/batch.rs:31-50
   SignatureError.{InvalidPublicKey, InvalidSignature}     src/error.rs:13-31
   *_LENGTH constants                         src/constants.rs:12-30
@@ -27,7 +29,7 @@ LIB_PATH = os.environ.get("SSA_LIB") or os.path.join(_HERE, "csrc", "libschnorr_
 SCALAR_LENGTH = 32
 PRIVATE_KEY_LENGTH = 32
 BASEFIELD_LENGTH = 48
-PUBLIC_KEY_LENGTH = 49          # compressed wire form (decompression is a "next" row)
+PUBLIC_KEY_LENGTH = 49          # compressed wire form (ssa_compress_many / ssa_decompress_many)
 AFFINE_PUBLIC_KEY_LENGTH = 96   # in-memory AffinePoint (x, y): what the engine consumes
 KEY_PAIR_LENGTH = 32
 SIGNATURE_LENGTH = 81
@@ -38,6 +40,8 @@ FLAG_CHECK_TORSION = 1
 FLAG_FORCE_LANE = 2   # throughput kernels (one signature per lane) whatever the batch size
 FLAG_FORCE_COOP = 4   # low-latency kernel (one wave per signature) whatever the batch size
 FLAG_SIG_FLAG_BYTE = 8  # verify_batch's semantics for byte 48 of the signature (src/batch.rs:104)
+FLAG_SIGN_CT = 16       # constant-time signing (the reference's `&BASEPOINT_TABLE * r`, src/signature.rs:67,116)
+FLAG_SIGN_KEYED = 32    # 130-byte KeyedSignature records out (src/signature.rs:237-245)
 KEYSET_KINDS = {"auto": 0, "comb": 1, "ladder": 2}
 _MODE_FLAGS = {None: 0, "auto": 0, "lane": FLAG_FORCE_LANE, "coop": FLAG_FORCE_COOP}
 
@@ -140,6 +144,10 @@ def _load():
         "ssa_msm_combine_device": (i32, [vp, vp, sz, vp]),
         "ssa_msm_combine": (i32, [vp, vp, sz]),
         "ssa_abi_version": (i32, []),
+        "ssa_keygen_sign_many_ex": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, vp]),
+        "ssa_keygen_sign_many_ex_device": (i32, [vp, vp, vp, vp, vp, sz, sz, sz, u32, vp, vp]),
+        "ssa_compress_many": (i32, [vp, vp, vp, sz, vp, vp]),
+        "ssa_compress_many_device": (i32, [vp, vp, vp, sz, vp, vp]),
         "ssa_ctx_stream_release": (i32, [vp, vp]),
         "ssa_ctx_stream_acquire": (i32, [vp, vp]),
         "ssa_debug_fault_after_chunk": (i32, [vp, i32]),
@@ -346,15 +354,29 @@ class Engine:
                "ssa_rescue_hash_many")
         return out
 
-    def keygen_sign_many(self, sks, nonces, msgs, offsets=None):
+    def keygen_sign_many(self, sks, nonces, msgs, offsets=None, constant_time=False, keyed=False):
+        """pk_i = [sk_i]G and sig_i = sign(sk_i, nonce_i, msg_i) -> (pks uint8[n, 96], sigs uint8[n, 81]).
+        constant_time: SSA_FLAG_SIGN_CT (same bytes, no secret-dependent branch or address).
+        keyed: the second array holds 130-byte KeyedSignature records pk(49) || sig(81) instead."""
         sks, nonces = _np_u8(sks, 32), _np_u8(nonces, 32)
         n = sks.shape[0]
         m, off, stride, mlen = self._msg_args(msgs, offsets, n)
         pks = np.zeros((n, 96), dtype=np.uint8)
-        sigs = np.zeros((n, 81), dtype=np.uint8)
-        _check(_lib.ssa_keygen_sign_many(self._ctx, _ptr(sks), _ptr(nonces), _ptr(m), _ptr(off), stride, mlen, n,
-                                         _ptr(pks), _ptr(sigs)), "ssa_keygen_sign_many")
+        sigs = np.zeros((n, 130 if keyed else 81), dtype=np.uint8)
+        flags = (FLAG_SIGN_CT if constant_time else 0) | (FLAG_SIGN_KEYED if keyed else 0)
+        _check(_lib.ssa_keygen_sign_many_ex(self._ctx, _ptr(sks), _ptr(nonces), _ptr(m), _ptr(off), stride, mlen, n,
+                                            flags, _ptr(pks), _ptr(sigs)), "ssa_keygen_sign_many_ex")
         return pks, sigs
+
+    def compress_many(self, pks, pk_inf=None):
+        """PublicKey::to_bytes for n affine keys -> (uint8[n, 49], status uint8[n])"""
+        pks = _np_u8(pks, 96)
+        n = pks.shape[0]
+        inf = _np_u8(pk_inf) if pk_inf is not None else None
+        out = np.zeros((n, 49), dtype=np.uint8)
+        st = np.full(n, 255, dtype=np.uint8)
+        _check(_lib.ssa_compress_many(self._ctx, _ptr(pks), _ptr(inf), n, _ptr(out), _ptr(st)), "ssa_compress_many")
+        return out, st
 
     def verify_keyed_many(self, keyed, msgs, offsets=None, check_torsion=True):
         """n x KeyedSignature::verify on 130-byte records pk(49) || sig(81) -> (status, n_fail)."""
@@ -457,10 +479,15 @@ class Engine:
                                            flags, d_status, d_nfail), "ssa_verify_many_device")
 
     def keygen_sign_many_device(self, d_sks, d_nonces, d_msgs, n, msg_len, d_pks, d_sigs, msg_stride=None,
-                                d_offsets=0):
-        _check(_lib.ssa_keygen_sign_many_device(self._ctx, d_sks, d_nonces, d_msgs, d_offsets or None,
-                                                msg_stride if msg_stride is not None else msg_len, msg_len, n,
-                                                d_pks, d_sigs), "ssa_keygen_sign_many_device")
+                                d_offsets=0, constant_time=False, keyed=False):
+        flags = (FLAG_SIGN_CT if constant_time else 0) | (FLAG_SIGN_KEYED if keyed else 0)
+        _check(_lib.ssa_keygen_sign_many_ex_device(self._ctx, d_sks, d_nonces, d_msgs, d_offsets or None,
+                                                   msg_stride if msg_stride is not None else msg_len, msg_len, n, flags,
+                                                   d_pks or None, d_sigs), "ssa_keygen_sign_many_ex_device")
+
+    def compress_many_device(self, d_pks, n, d_out, d_pk_inf=0, d_status=0):
+        _check(_lib.ssa_compress_many_device(self._ctx, d_pks, d_pk_inf or None, n, d_out, d_status or None),
+               "ssa_compress_many_device")
 
     def rescue_hash_many_device(self, d_felts, per_row, n, d_out):
         _check(_lib.ssa_rescue_hash_many_device(self._ctx, d_felts, per_row, n, d_out),
@@ -627,18 +654,13 @@ class PublicKey:
             return None
         return cls(pks[0].tobytes(), is_identity=bool(inf[0]))
 
-    def to_bytes(self):
-        """PublicKey::to_bytes (src/public.rs:49-51): x || flag byte (formatting only, no arithmetic)."""
-        if self.is_identity:
-            return bytes(48) + bytes([0x80])
-        p = 2**64 - 2**32 + 1
-        flag = 0
-        for i in range(5, -1, -1):
-            c = int.from_bytes(self.affine[48 + 8 * i: 56 + 8 * i], "little")
-            if c:
-                flag = 0x40 if c > (p - 1) // 2 else 0
-                break
-        return self.affine[:48] + bytes([flag])
+    def to_bytes(self, engine=None):
+        """PublicKey::to_bytes (src/public.rs:49-51): x || flag byte, through ssa_compress_many."""
+        out, st = (engine or default_engine()).compress_many(np.frombuffer(self.affine, np.uint8),
+                                                             pk_inf=np.array([1 if self.is_identity else 0], np.uint8))
+        if st[0] != OK:
+            raise MalformedInput("PublicKey holds a non-canonical limb")
+        return out[0].tobytes()
 
     def __eq__(self, o):
         return isinstance(o, PublicKey) and o.affine == self.affine and o.is_identity == self.is_identity
@@ -706,8 +728,8 @@ class KeyedSignature:
         self.public_key = public_key
         self.signature = signature
 
-    def to_bytes(self):  # src/signature.rs:236-243
-        return self.public_key.to_bytes() + self.signature.to_bytes()
+    def to_bytes(self, engine=None):  # src/signature.rs:236-243
+        return self.public_key.to_bytes(engine) + self.signature.to_bytes()
 
     @classmethod
     def from_bytes(cls, b130, engine=None):  # src/signature.rs:246-271: None unless both halves decode
@@ -739,23 +761,35 @@ class KeyPair:
     def from_private(cls, sk, engine=None):  # PublicKey::from(&PrivateKey), src/public.rs:26-32
         eng = engine or default_engine()
         pks, _ = eng.keygen_sign_many(np.frombuffer(sk.bytes, np.uint8), np.frombuffer(sk.bytes, np.uint8),
-                                      np.zeros((1, 1), np.uint8))
+                                      np.zeros((1, 1), np.uint8), constant_time=True)
         return cls(sk, PublicKey(pks[0].tobytes()))
 
-    def sign(self, message, rng, engine=None):  # src/signature.rs:114-129
+    def _nonce(self, rng):  # Scalar::random: 64 random bytes mod q, never 0
+        while True:
+            v = int.from_bytes(rng(64), "little") % Q
+            if v:
+                return v.to_bytes(32, "little")
+
+    def sign(self, message, rng, engine=None):  # src/signature.rs:114-129 (constant-time, like the reference)
         eng = engine or default_engine()
-        nonce = (int.from_bytes(rng(64), "little") % Q).to_bytes(32, "little")
         msg = np.frombuffer(bytes(message) + b"\0", np.uint8).copy()
         off = np.array([0, len(message)], dtype=np.uint64)
         _, sigs = eng.keygen_sign_many(np.frombuffer(self.private_key.bytes, np.uint8),
-                                       np.frombuffer(nonce, np.uint8), msg, offsets=off)
+                                       np.frombuffer(self._nonce(rng), np.uint8), msg, offsets=off, constant_time=True)
         return Signature(sigs[0].tobytes())
 
     def verify_signature(self, signature, message):  # src/signature.rs:159-165
         return signature.verify(message, self.public_key)
 
     def sign_and_bind_pkey(self, message, rng, engine=None):  # src/signature.rs:132-156
-        return KeyedSignature(self.public_key, self.sign(message, rng, engine))
+        """the engine emits the 130-byte record pk(49) || sig(81) itself (SSA_FLAG_SIGN_KEYED)"""
+        eng = engine or default_engine()
+        msg = np.frombuffer(bytes(message) + b"\0", np.uint8).copy()
+        off = np.array([0, len(message)], dtype=np.uint64)
+        _, recs = eng.keygen_sign_many(np.frombuffer(self.private_key.bytes, np.uint8),
+                                       np.frombuffer(self._nonce(rng), np.uint8), msg, offsets=off, constant_time=True,
+                                       keyed=True)
+        return KeyedSignature(self.public_key, Signature(recs[0, 49:].tobytes()))
 
 
 def verify_batch(signatures, public_keys, messages, rng=None, engine=None, msm=False):

@@ -182,7 +182,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
                       &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
                       &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
-                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs})
+                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
@@ -392,19 +392,23 @@ static int verify_launch(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_p
     return 0;
 }
 
-extern "C" int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces,
-                                           const uint8_t *d_msgs, const uint64_t *d_msg_off,
-                                           size_t msg_stride, size_t msg_len, size_t n,
-                                           uint8_t *d_pks_out, uint8_t *d_sigs_out) {
-    if (!ctx || (n && (!d_sks || !d_nonces || !d_pks_out || !d_sigs_out))) return SSA_ERR_ARG;
-    if (int rc = check_msgs(d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
-    if (n == 0) return 0;
-    HIP_TRY(hipSetDevice(ctx->device));
+// the throughput (variable-time) signer's launch; arguments checked by the caller (ssa_sign.hip)
+int ssa_internal_sign_vartime(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces, const uint8_t *d_msgs,
+                              const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n, uint8_t *d_pks_out,
+                              uint8_t *d_sigs_out) {
     MsgView mv{d_msgs, d_msg_off, msg_stride, msg_len};
     return timed_launch(ctx, "ssa_k_sign", [&] {
         hipLaunchKernelGGL(ssa_k_sign, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
                            (const u64 *)ctx->d_gtab, d_sks, d_nonces, mv, n, d_pks_out, d_sigs_out);
     });
+}
+
+extern "C" int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces,
+                                           const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                           size_t msg_stride, size_t msg_len, size_t n,
+                                           uint8_t *d_pks_out, uint8_t *d_sigs_out) {
+    return ssa_keygen_sign_many_ex_device(ctx, d_sks, d_nonces, d_msgs, d_msg_off, msg_stride, msg_len, n, 0u, d_pks_out,
+                                          d_sigs_out);
 }
 
 extern "C" int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t n,
@@ -562,40 +566,8 @@ extern "C" int ssa_rescue_hash_many(ssa_ctx *ctx, const uint64_t *felts, uint32_
 extern "C" int ssa_keygen_sign_many(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces,
                                     const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
                                     size_t msg_len, size_t n, uint8_t *pks_out, uint8_t *sigs_out) {
-    if (!ctx || (n && (!sks || !nonces || !pks_out || !sigs_out))) return SSA_ERR_ARG;
-    if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
-    if (n == 0) return 0;
-    // secret keys and nonces are canonical non-zero scalars: PrivateKey::new / Scalar::random never yield 0 or a
-    // value >= q (src/private.rs:49-57); a caller that reduced 32 random bytes itself would hand over biased nonces
-    static const uint8_t q_le[32] = {0xcf, 0xac, 0xd4, 0xae, 0x3e, 0x62, 0x43, 0xd4, 0x22, 0x77, 0x15,
-                                     0x30, 0x23, 0xa7, 0x7a, 0x32, 0xb5, 0x37, 0x0a, 0x99, 0x0f, 0xbf,
-                                     0x3f, 0x56, 0xd0, 0x22, 0x3f, 0x3b, 0x9b, 0x59, 0xf2, 0x7a};
-    auto canonical_nonzero = [](const uint8_t *v) {
-        bool zero = true;
-        int cmp = 0;   // sign of v - q, decided from the most significant byte down
-        for (int k = 31; k >= 0; k--) {
-            zero = zero && v[k] == 0;
-            if (cmp == 0 && v[k] != q_le[k]) cmp = v[k] < q_le[k] ? -1 : 1;
-        }
-        return !zero && cmp < 0;
-    };
-    for (size_t i = 0; i < n; i++)
-        if (!canonical_nonzero(sks + 32 * i) || !canonical_nonzero(nonces + 32 * i)) return SSA_ERR_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    StagedInputs s;
-    const void *p_sk, *p_nonce;
-    if (int rc = stage_up(ctx, ctx->st_sigs, sks, n * 32, &p_sk)) return rc;
-    if (int rc = stage_up(ctx, ctx->st_pks, nonces, n * 32, &p_nonce)) return rc;
-    if (int rc = stage_msgs(ctx, msgs, msg_off, msg_stride, msg_len, n, s)) return rc;
-    if (ctx->st_aux.reserve(n * 96) || ctx->st_aux2.reserve(n * 81)) return SSA_ERR_HIP;
-    if (int rc = ssa_keygen_sign_many_device(ctx, (const u8 *)p_sk, (const u8 *)p_nonce, s.msgs, s.off,
-                                             msg_stride, msg_len, n, (u8 *)ctx->st_aux.p,
-                                             (u8 *)ctx->st_aux2.p))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(pks_out, ctx->st_aux.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(sigs_out, ctx->st_aux2.p, n * 81, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return 0;
+    if (n && !pks_out) return SSA_ERR_ARG;
+    return ssa_keygen_sign_many_ex(ctx, sks, nonces, msgs, msg_off, msg_stride, msg_len, n, 0u, pks_out, sigs_out);
 }
 
 extern "C" int ssa_decompress_many(ssa_ctx *ctx, const uint8_t *compressed, size_t n, uint8_t *pks_out,

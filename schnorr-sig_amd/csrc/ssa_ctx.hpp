@@ -89,6 +89,10 @@ struct ssa_ctx {
     // combined like the shards of a multi-GPU batch.  SSA_LANE_SLICE / SSA_MSM_SLICE override (tests force small ones).
     size_t lane_slice = (size_t)1 << 20, msm_slice = (size_t)1 << 24;
     DevBuf msm_slice_recs;        // one 24-word record per MSM slice
+    // signing (ssa_sign.hip): the 4-bit comb table of the constant-time signer (98 KB, built at the first use) and the
+    // intermediates of the keyed (130-byte) output
+    DevBuf ctab, sg_sigs, sg_pks;
+    bool ctab_ready = false;
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;
     std::vector<struct ssa_keyset *> keysets;   // live key sets of this context (orphaned, not leaked, by ssa_ctx_destroy)

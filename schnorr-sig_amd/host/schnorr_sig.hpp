@@ -4,7 +4,11 @@
 // INTEGRATION.md) and these classes are interchangeable callers of the same entry points.
 //
 //   schnorr_sig::Signature::verify          <- src/signature.rs:181-205
-//   schnorr_sig::KeyPair::{create, sign, verify_signature}  <- src/keypair.rs:57-65, src/signature.rs:114-165
+//   schnorr_sig::KeyPair::{create, sign, sign_and_bind_pkey, verify_signature}
+//                                           <- src/keypair.rs:57-65, src/signature.rs:114-165 (signing is CONSTANT-TIME,
+//                                              SSA_FLAG_SIGN_CT, like the reference's `&BASEPOINT_TABLE * r`)
+//   schnorr_sig::PublicKey::{to_bytes, from_bytes}          <- src/public.rs:49-56
+//   schnorr_sig::KeyedSignature::{to_bytes, from_bytes, verify}  <- src/signature.rs:232-271
 //   schnorr_sig::PublicKey::verify_signature <- src/signature.rs:170-176
 //   schnorr_sig::verify_batch               <- src/batch.rs:31-50
 //   schnorr_sig::SignatureError             <- src/error.rs:13-31
@@ -79,6 +83,26 @@ struct PublicKey {  // src/public.rs:24 -- the in-memory AffinePoint (x, y), can
     std::array<uint8_t, AFFINE_PUBLIC_KEY_LENGTH> affine{};
     bool is_identity = false;  // AffinePoint::identity() is a valid PublicKey (src/public.rs:95-101)
     Result verify_signature(Context &cx, const Signature &sig, const uint8_t *msg, size_t len) const;
+    // PublicKey::to_bytes, src/public.rs:49-51: the 49-byte compressed wire form
+    std::array<uint8_t, PUBLIC_KEY_LENGTH> to_bytes(Context &cx) const {
+        std::array<uint8_t, PUBLIC_KEY_LENGTH> out{};
+        const uint8_t inf = is_identity ? 1 : 0;
+        uint8_t st = SSA_MALFORMED;
+        const int rc = ssa_compress_many(cx.get(), affine.data(), &inf, 1, out.data(), &st);
+        if (rc != 0) throw std::runtime_error(std::string("ssa_compress_many: ") + ssa_strerror(rc));
+        if (st != SSA_OK) throw Panic("PublicKey holds a non-canonical limb");
+        return out;
+    }
+    // PublicKey::from_bytes, src/public.rs:54-56: nullopt when decompression fails (CtOption is_none)
+    static std::optional<PublicKey> from_bytes(Context &cx, const std::array<uint8_t, PUBLIC_KEY_LENGTH> &b) {
+        PublicKey pk;
+        uint8_t inf = 0, st = 1;
+        const int rc = ssa_decompress_many(cx.get(), b.data(), 1, pk.affine.data(), &inf, &st);
+        if (rc != 0) throw std::runtime_error(std::string("ssa_decompress_many: ") + ssa_strerror(rc));
+        if (st != 0) return std::nullopt;
+        pk.is_identity = inf != 0;
+        return pk;
+    }
 };
 
 struct Signature {  // src/signature.rs:34-40, wire layout :208-214
@@ -97,6 +121,36 @@ struct Signature {  // src/signature.rs:34-40, wire layout :208-214
 inline Result PublicKey::verify_signature(Context &cx, const Signature &sig, const uint8_t *msg, size_t len) const {
     return sig.verify(cx, msg, len, *this);
 }
+
+struct KeyedSignature {  // src/signature.rs:55-60; wire form pk(49) || sig(81), :236-271
+    PublicKey public_key;
+    Signature signature;
+    Result verify(Context &cx, const uint8_t *msg, size_t len) const { return signature.verify(cx, msg, len, public_key); }
+    std::array<uint8_t, KEYED_SIGNATURE_LENGTH> to_bytes(Context &cx) const {
+        std::array<uint8_t, KEYED_SIGNATURE_LENGTH> out{};
+        const auto pk = public_key.to_bytes(cx);
+        std::memcpy(out.data(), pk.data(), PUBLIC_KEY_LENGTH);
+        std::memcpy(out.data() + PUBLIC_KEY_LENGTH, signature.bytes.data(), SIGNATURE_LENGTH);
+        return out;
+    }
+    // nullopt unless both halves decode (the scalar e must be canonical: Signature::from_bytes, src/signature.rs:217-227)
+    static std::optional<KeyedSignature> from_bytes(Context &cx, const std::array<uint8_t, KEYED_SIGNATURE_LENGTH> &b) {
+        std::array<uint8_t, PUBLIC_KEY_LENGTH> pkb;
+        std::memcpy(pkb.data(), b.data(), PUBLIC_KEY_LENGTH);
+        const auto pk = PublicKey::from_bytes(cx, pkb);
+        static const uint8_t q_le[32] = {0xcf, 0xac, 0xd4, 0xae, 0x3e, 0x62, 0x43, 0xd4, 0x22, 0x77, 0x15,
+                                         0x30, 0x23, 0xa7, 0x7a, 0x32, 0xb5, 0x37, 0x0a, 0x99, 0x0f, 0xbf,
+                                         0x3f, 0x56, 0xd0, 0x22, 0x3f, 0x3b, 0x9b, 0x59, 0xf2, 0x7a};
+        int cmp = 0;
+        for (int k = 31; k >= 0 && cmp == 0; k--)
+            if (b[PUBLIC_KEY_LENGTH + 49 + k] != q_le[k]) cmp = b[PUBLIC_KEY_LENGTH + 49 + k] < q_le[k] ? -1 : 1;
+        if (!pk || cmp >= 0) return std::nullopt;
+        KeyedSignature ks;
+        ks.public_key = *pk;
+        std::memcpy(ks.signature.bytes.data(), b.data() + PUBLIC_KEY_LENGTH, SIGNATURE_LENGTH);
+        return ks;
+    }
+};
 
 struct KeyPair {  // src/keypair.rs:48-53
     PrivateKey private_key;
@@ -148,21 +202,34 @@ struct KeyPair {  // src/keypair.rs:48-53
         KeyPair kp;
         random_scalar(rng, kp.private_key.bytes.data());
         uint8_t sig[SIGNATURE_LENGTH], msg = 0;
-        int rc = ssa_keygen_sign_many(cx.get(), kp.private_key.bytes.data(), kp.private_key.bytes.data(), &msg,
-                                      nullptr, 1, 1, 1, kp.public_key.affine.data(), sig);
-        if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many: ") + ssa_strerror(rc));
+        int rc = ssa_keygen_sign_many_ex(cx.get(), kp.private_key.bytes.data(), kp.private_key.bytes.data(), &msg,
+                                         nullptr, 1, 1, 1, SSA_FLAG_SIGN_CT, kp.public_key.affine.data(), sig);
+        if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many_ex: ") + ssa_strerror(rc));
         return kp;
     }
-    // KeyPair::sign, src/signature.rs:114-129
+    // KeyPair::sign, src/signature.rs:114-129 (constant-time in the key and the nonce, like the reference)
     Signature sign(Context &cx, const uint8_t *msg, size_t len, Rng rng) const {
         uint8_t nonce[32], pk[AFFINE_PUBLIC_KEY_LENGTH];
         random_scalar(rng, nonce);
         Signature s;
         uint8_t dummy = 0;
-        int rc = ssa_keygen_sign_many(cx.get(), private_key.bytes.data(), nonce, len ? msg : &dummy, nullptr, len,
-                                      len, 1, pk, s.bytes.data());
-        if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many: ") + ssa_strerror(rc));
+        int rc = ssa_keygen_sign_many_ex(cx.get(), private_key.bytes.data(), nonce, len ? msg : &dummy, nullptr, len,
+                                         len, 1, SSA_FLAG_SIGN_CT, pk, s.bytes.data());
+        if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many_ex: ") + ssa_strerror(rc));
         return s;
+    }
+    // KeyPair::sign_and_bind_pkey, src/signature.rs:132-156: the engine emits the 130-byte record itself
+    // (SSA_FLAG_SIGN_KEYED); the public key inside it is this pair's
+    KeyedSignature sign_and_bind_pkey(Context &cx, const uint8_t *msg, size_t len, Rng rng) const {
+        uint8_t nonce[32], rec[KEYED_SIGNATURE_LENGTH], dummy = 0;
+        random_scalar(rng, nonce);
+        int rc = ssa_keygen_sign_many_ex(cx.get(), private_key.bytes.data(), nonce, len ? msg : &dummy, nullptr, len,
+                                         len, 1, SSA_FLAG_SIGN_CT | SSA_FLAG_SIGN_KEYED, nullptr, rec);
+        if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many_ex: ") + ssa_strerror(rc));
+        KeyedSignature ks;
+        ks.public_key = public_key;
+        std::memcpy(ks.signature.bytes.data(), rec + PUBLIC_KEY_LENGTH, SIGNATURE_LENGTH);
+        return ks;
     }
     Result verify_signature(Context &cx, const Signature &sig, const uint8_t *msg, size_t len) const {
         return sig.verify(cx, msg, len, public_key);  // src/signature.rs:159-165

@@ -48,6 +48,37 @@ int main() {
     r = e0.verify(cx, message, sizeof message, kp.public_key);
     CHECK(r && *r == SignatureError::InvalidSignature);
 
+    // wire forms of the signing side (src/public.rs:49-56, src/signature.rs:132-156,232-271)
+    {
+        const auto pkb = kp.public_key.to_bytes(cx);
+        CHECK((pkb[48] & 0x3f) == 0 && std::memcmp(pkb.data(), kp.public_key.affine.data(), 48) == 0);
+        const auto back = PublicKey::from_bytes(cx, pkb);
+        CHECK(back && back->affine == kp.public_key.affine && !back->is_identity);
+        KeyedSignature ks = kp.sign_and_bind_pkey(cx, message, sizeof message, rng);
+        CHECK(ks.public_key.affine == kp.public_key.affine);
+        CHECK(!ks.verify(cx, message, sizeof message));
+        const auto rec = ks.to_bytes(cx);
+        CHECK(std::memcmp(rec.data(), pkb.data(), 49) == 0);
+        const auto ks2 = KeyedSignature::from_bytes(cx, rec);
+        CHECK(ks2 && !ks2->verify(cx, message, sizeof message) && ks2->signature.bytes == ks.signature.bytes);
+        Result rw = ks2->verify(cx, wrong, sizeof wrong);
+        CHECK(rw && *rw == SignatureError::InvalidSignature);
+        auto bad = rec;
+        bad[48] = 0xff;                                            // src/public.rs:150-156
+        CHECK(!KeyedSignature::from_bytes(cx, bad));
+        bad = rec;
+        bad[129] = 0x7f;                                           // e >= q: Signature::from_bytes is_none
+        CHECK(!KeyedSignature::from_bytes(cx, bad));
+        PublicKey idk;
+        idk.is_identity = true;
+        const auto idb = idk.to_bytes(cx);
+        bool id_ok = idb[48] == 0x80;
+        for (int k = 0; k < 48; k++) id_ok = id_ok && idb[k] == 0;
+        CHECK(id_ok);                                              // src/public.rs:95-101
+        const auto idr = PublicKey::from_bytes(cx, idb);
+        CHECK(idr && idr->is_identity);
+    }
+
     // verify_five_signatures, src/batch.rs:152-179
     const char *texts[5] = {"Message1", "Message2", "Message3", "Message4", "Message5"};
     std::vector<KeyPair> kps;

@@ -262,3 +262,119 @@ def test_msm_partial_on_its_own_stream_is_ordered_by_msm_verdict():
         assert int(verdict.cpu().item()) == 3
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------- the signing side: constant-time mode, wire forms
+def _scalars_le(values):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in values), np.uint8).reshape(-1, 32).copy()
+
+
+EDGE_SCALARS = [1, 2, 15, 16, 17, Q - 1, Q - 2, 1 << 252, (1 << 252) + 1, int("1" * 63, 16), int("6" + "f" * 63, 16),
+                int("0f" * 32, 16) % Q, int("f0" * 31 + "70", 16), 16**63, 16**32 - 1, (Q - 1) // 2]
+
+
+def test_constant_time_signer_bytes_equal_oracle_and_throughput_signer(engine, oracle):
+    """SSA_FLAG_SIGN_CT (the reference's constant-time `&BASEPOINT_TABLE * r`, src/signature.rs:67,116,123): the same
+    bytes as the throughput signer and as the oracle's signer (src/signature.rs:114-129), random and edge scalars --
+    one set digit, all digits 15, q - 1 --, ragged messages incl. empty ones; every signature verifies"""
+    rng = np.random.default_rng(4400)
+    edge = [v for v in EDGE_SCALARS if 0 < v < Q]
+    n = 600
+    vals_sk = edge + [int.from_bytes(rng.bytes(64), "little") % Q or 1 for _ in range(n - len(edge))]
+    vals_r = edge[::-1] + [int.from_bytes(rng.bytes(64), "little") % Q or 1 for _ in range(n - len(edge))]
+    sks, nonces = _scalars_le(vals_sk), _scalars_le(vals_r)
+    lens = rng.integers(0, 200, size=n)
+    lens[:4] = [0, 7, 14, 1]
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    flat = rng.integers(0, 256, size=int(off[-1]) + 1, dtype=np.uint8)
+    pk_v, sig_v = engine.keygen_sign_many(sks, nonces, flat, offsets=off)
+    pk_c, sig_c = engine.keygen_sign_many(sks, nonces, flat, offsets=off, constant_time=True)
+    assert (pk_c == pk_v).all() and (sig_c == sig_v).all()
+    m = 96
+    pk_o, sig_o = oracle.keygen_sign_many(sks[:m], nonces[:m], flat, offsets=off[:m + 1])
+    assert (pk_c[:m] == pk_o).all() and (sig_c[:m] == sig_o).all()
+    st, nf = engine.verify_many(sig_c, pk_c, flat, offsets=off, check_torsion=True)
+    assert nf == 0
+    # the host form refuses 0 and values >= q in both modes (PrivateKey::new / Scalar::random never yield them)
+    for ct in (False, True):
+        for bad in (0, Q, Q + 5, (1 << 256) - 1):
+            s2 = sks[:3].copy()
+            s2[1] = _scalars_le([bad])[0]
+            with pytest.raises(RuntimeError, match="invalid argument"):
+                engine.keygen_sign_many(s2, nonces[:3], flat, offsets=off[:4], constant_time=ct)
+            with pytest.raises(RuntimeError, match="invalid argument"):
+                engine.keygen_sign_many(sks[:3], s2, flat, offsets=off[:4], constant_time=ct)
+
+
+def test_constant_time_signer_device_form_reduces_and_falls_back(engine):
+    """the _device form cannot refuse a lane: scalars are reduced mod q; a scalar that reduces to 0 drives the
+    constant-time walk onto B - B, the lane is flagged and recomputed by the exact code -- same bytes as the
+    throughput signer (identity key / identity R encodings included)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    vals_sk = [Q, 5, Q + 3, 2 * Q, 7, 11]
+    vals_r = [9, Q, 2 * Q + 1, 13, (1 << 256) - 1, 1]
+    n = len(vals_sk)
+    msgs = np.random.default_rng(4500).integers(0, 256, size=(n, 33), dtype=np.uint8)
+    d_sk, d_r, d_m = (torch.from_numpy(a).to(dev) for a in (_scalars_le(vals_sk), _scalars_le(vals_r), msgs))
+    outs = []
+    for ct in (False, True):
+        pks = torch.full((n, 96), 0xAA, dtype=torch.uint8, device=dev)
+        sigs = torch.full((n, 81), 0xAA, dtype=torch.uint8, device=dev)
+        engine.keygen_sign_many_device(d_sk.data_ptr(), d_r.data_ptr(), d_m.data_ptr(), n, 33, pks.data_ptr(),
+                                       sigs.data_ptr(), constant_time=ct)
+        engine.sync()
+        outs.append((pks.cpu().numpy(), sigs.cpu().numpy()))
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+    pks, sigs = outs[1]
+    assert not pks[0].any() and not pks[3].any()                # sk = 0: the identity key, (0, 0) in affine bytes
+    assert not sigs[1, :48].any() and sigs[1, 48] == 0x80       # nonce = 0: R is the identity, [0; 48] || 0x80
+    st, nf = engine.verify_many(sigs, pks, msgs, check_torsion=False, pk_inf=(~pks.any(axis=1)).astype(np.uint8))
+    assert (st[[2, 4, 5]] == 0).all()                           # ordinary lanes (scalars reduced) verify
+
+
+def test_keyed_records_and_compression_round_trip(engine, oracle):
+    """SSA_FLAG_SIGN_KEYED: 130-byte KeyedSignature records pk(49) || sig(81) straight from the signer
+    (sign_and_bind_pkey + KeyedSignature::to_bytes, src/signature.rs:132-156,237-245), both signers; the 49 bytes are
+    PublicKey::to_bytes (src/public.rs:49-51) = the oracle's compression; the records verify through
+    ssa_verify_keyed_many; ssa_compress_many inverts ssa_decompress_many"""
+    rng = np.random.default_rng(4600)
+    n = 300
+    sks, nonces = make_scalars(rng, n), make_scalars(rng, n)
+    msgs = rng.integers(0, 256, size=(n, 40), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    for ct in (False, True):
+        pk2, recs = engine.keygen_sign_many(sks, nonces, msgs, constant_time=ct, keyed=True)
+        assert recs.shape == (n, 130) and (pk2 == pks).all() and (recs[:, 49:] == sigs).all()
+        for i in range(0, n, 7):
+            assert recs[i, :49].tobytes() == oracle.compress(pks[i].tobytes())
+        st, nf = engine.verify_keyed_many(recs, msgs, check_torsion=True)
+        assert nf == 0
+        recs[5, 60] ^= 1
+        st, nf = engine.verify_keyed_many(recs, msgs, check_torsion=True)
+        assert nf == 1 and st[5] == 2
+    comp, st = engine.compress_many(pks)
+    assert (st == 0).all() and (comp == recs[:, :49]).all()
+    back, inf, dst = engine.decompress_many(comp)
+    assert (dst == 0).all() and not inf.any() and (back == pks).all()
+    # the identity and a non-canonical limb
+    pk3 = pks[:4].copy()
+    pk3[2, 8:16] = 0xFF                                          # limb 1 of x = 2^64 - 1 >= p
+    inf3 = np.array([0, 1, 0, 0], np.uint8)
+    comp3, st3 = engine.compress_many(pk3, pk_inf=inf3)
+    assert list(st3) == [0, 0, 3, 0]
+    assert comp3[1].tobytes() == bytes(48) + b"\x80" == oracle.compress(pk3[1].tobytes(), pk_inf=True)
+    assert not comp3[2].any()
+    # the object mirror goes through the same entry points
+    import schnorr_sig_amd as ssa
+    import random
+    pyrng = random.Random(7)
+    kp = ssa.KeyPair.new(lambda k: bytes(pyrng.getrandbits(8) for _ in range(k)), engine)
+    ks = kp.sign_and_bind_pkey(b"keyed message", lambda k: bytes(pyrng.getrandbits(8) for _ in range(k)), engine)
+    raw = ks.to_bytes(engine)
+    assert len(raw) == 130 and raw[:49] == kp.public_key.to_bytes(engine) == oracle.compress(kp.public_key.affine)
+    ks2 = ssa.KeyedSignature.from_bytes(raw, engine)
+    assert ks2 is not None and ks2.verify(b"keyed message", engine) is None
+    with pytest.raises(ssa.SignatureError):
+        ks2.verify(b"another message", engine)
