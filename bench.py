@@ -521,6 +521,11 @@ def main():
     if legs and rank == 0 and n > 0 and hasattr(eng, "keyset_create"):
         keyed = guarded(keyed_leg, torch, eng, dev, g, min(n, 1 << 20))
 
+    # ---- the signing side: keygen + sign per second, throughput and constant-time signers ----
+    signing = None
+    if legs and rank == 0 and n > 0:
+        signing = guarded(signing_leg, torch, eng, dev, g, min(n, 1 << 18))
+
     # ---- config 4 beside the weak run: one 2^22 batch, rank 0 -> shards, verified once per step ----
     config4 = None
     if legs and rk.dist is not None and not strong and not args.no_strong_leg:
@@ -578,6 +583,7 @@ def main():
             "verify_batch_msm_form": msm,
             "host_path": host_path,
             "keyed_context": keyed,
+            "signing": signing,
             "scatter_ms": scatter_ms,
             "broadcast_ms": broadcast_ms,
             "config4_strong": config4,
@@ -673,6 +679,39 @@ def strong_leg(rk, eng, total):
             "scatter_ms": scatter_ms, "broadcast_ms": broadcast_ms,
             "verifications_per_sec_including_scatter": total / (dt + scatter_ms * 1e-3),
             "rejected": int(nfail.item())}
+
+
+def signing_leg(torch, eng, dev, g, n):
+    """KeyPair::new + KeyPair::sign for n (sk, nonce, 80-byte message) triples resident in HBM: the throughput signer
+    (16-bit comb, variable time) and the constant-time one (SSA_FLAG_SIGN_CT: 4-bit windows, full-table scans, what the
+    reference's `&BASEPOINT_TABLE * r` is); the two must emit the same bytes"""
+    sks = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    nonces = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    for t in (sks, nonces):
+        t[:, 31] &= 0x3F
+        t[:, 0] |= 1
+    msgs = torch.randint(0, 256, (n, 80), dtype=torch.uint8, device=dev, generator=g)
+    out = {"workload": "%d x (keygen + sign), 80-byte messages, inputs resident in HBM" % n}
+    res = {}
+    for name, ct in (("throughput_signer", False), ("constant_time_signer", True)):
+        pks = torch.empty((n, 96), dtype=torch.uint8, device=dev)
+        sigs = torch.empty((n, 81), dtype=torch.uint8, device=dev)
+
+        def run():
+            eng.keygen_sign_many_device(sks.data_ptr(), nonces.data_ptr(), msgs.data_ptr(), n, 80, pks.data_ptr(),
+                                        sigs.data_ptr(), constant_time=ct)
+        run()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            run()
+        eng.sync()
+        dt = (time.perf_counter() - t0) / 2
+        res[name] = (pks, sigs)
+        out[name] = {"signatures_per_sec": n / dt, "ms_per_batch": dt * 1e3}
+    out["same_bytes"] = bool((res["throughput_signer"][0] == res["constant_time_signer"][0]).all().item() and
+                             (res["throughput_signer"][1] == res["constant_time_signer"][1]).all().item())
+    return out
 
 
 def keyed_leg(torch, eng, dev, g, n, n_keys=64):

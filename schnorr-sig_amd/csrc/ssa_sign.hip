@@ -273,12 +273,24 @@ ssa_k_sign_ct(const DevParams *__restrict__ prm, const u64 *__restrict__ ctab, c
     sc256 h;
 #pragma unroll
     for (int k = 0; k < 4; k++) h.w[k] = d[k];
-    h = sc_reduce256(h);                                                   // :122 (the digest is public)
+    h = sc_reduce256_ct(h);      // :122 (the digest is public; the masked form keeps the kernel's instruction counts
+                                 //       independent of it too, which makes the PMC comparison of secret sets exact)
     sc256 e;
     ct_response(&e, &r, &sk, &h);                                          // :124
     u8 *sig = sigs_out + 81 * i;
     st_fp6(sig, rp.x);
-    sig[48] = jac_is_identity(rj) ? 0x80 : (f6_lex_largest(rp.y) ? 0x40 : 0x00);
+    // (R is public, but its flag is formed without branches as well: whether the 64 sort bits of a wave agree would
+    //  otherwise show in the kernel's instruction counts and blur the PMC comparison of secret sets)
+    u32 lex = 0u, decided = 0u;
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+        const u64 c = rp.y.c[k];                       // canonical (ct_to_aff)
+        const u32 nz = (u32)(c != 0ull), take = nz & ~decided & 1u;
+        lex = take ? (u32)(c > (FP_P - 1) / 2) : lex;
+        decided |= nz;
+    }
+    const u32 r_inf = (u32)f6_is_zero_ct(rj.Z);
+    sig[48] = (u8)(r_inf ? 0x80u : (lex << 6));
 #pragma unroll
     for (int k = 0; k < 4; k++) st_u64_le(sig + 49 + 8 * k, e.w[k]);
 }

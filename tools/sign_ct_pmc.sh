@@ -20,7 +20,7 @@ python3 - "$OUT" <<'PY' | tee $OUT/summary.txt
 import collections, csv, glob, sys
 out = sys.argv[1]
 print("# rocprofv3 --pmc SQ_INSTS_*: wave-instruction counts per launch of the signing kernel, three secret sets")
-print("# (a random, b sparse: sk = 1 / nonce = 2^252, c dense: every 4-bit window 15); n = 4096 lanes, same messages")
+print("# (a random, b sparse: sk = lane + 1 / nonce = 2^252 + lane + 1, c dense: nearly every 4-bit window 15); n = 4096 lanes, same messages")
 rows = {}
 for mode, kern in (("ct", "ssa_k_sign_ct"), ("vartime", "ssa_k_sign")):
     for s in "abc":

@@ -2,8 +2,8 @@
 """One launch of the signer on n lanes for ONE of three secret sets -- the dynamic side of the constant-time claim
 (SSA_FLAG_SIGN_CT; the reference signs with the constant-time `&BASEPOINT_TABLE * r`, src/signature.rs:67,116):
 
-    a  uniformly random scalars                       b  sparse: sk = 1, nonce = 2^252 (63 zero windows each)
-    c  dense: every window 15 (0x6fff...f), sk = nonce
+    a  uniformly random scalars         b  sparse: sk = lane + 1, nonce = 2^252 + lane + 1 (60 zero windows or more)
+    c  dense: 0x6fff...f minus a few bits of the lane index (nearly every window 15)
 
 Messages are the same in the three sets.  Run under `rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU ...`
 once per set (tools/sign_ct_pmc.sh): the counters of ssa_k_sign_ct must not depend on the set, those of the
@@ -30,16 +30,13 @@ def secrets(which, n):
             v = [int.from_bytes(rng.bytes(64), "little") % Q or 1 for _ in range(n)]
             return np.frombuffer(b"".join(x.to_bytes(32, "little") for x in v), np.uint8).reshape(n, 32).copy()
         return draw(), draw()
-    if which == "b":
-        sk = np.zeros((n, 32), np.uint8)
-        sk[:, 0] = 1
-        nonce = np.zeros((n, 32), np.uint8)
-        nonce[:, 31] = 0x10
-        return sk, nonce
-    dense = (0x6F << 248) | ((1 << 248) - 1)
-    assert dense < Q
-    d = np.frombuffer(dense.to_bytes(32, "little"), np.uint8)
-    return np.tile(d, (n, 1)).copy(), np.tile(d, (n, 1)).copy()
+    def pack(vals):
+        assert all(0 < v < Q for v in vals)
+        return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), np.uint8).reshape(n, 32).copy()
+    if which == "b":      # sparse: at most four non-zero windows per scalar (the lanes still differ from each other)
+        return pack([i + 1 for i in range(n)]), pack([(1 << 252) + i + 1 for i in range(n)])
+    dense = (0x6F << 248) | ((1 << 248) - 1)      # dense: every window 15 but the few the lane index clears
+    return pack([dense - (i << 40) for i in range(n)]), pack([dense - (i << 100) - 1 for i in range(n)])
 
 
 def main():
