@@ -150,7 +150,7 @@ int ssa_verify_batch(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, cons
  * NULL for 128-bit coefficients from a ChaCha20 stream (RFC 8439) generated on the device and keyed per
  * call with getrandom(2).  Returns SSA_OK, SSA_INVALID_SIGNATURE, or
  * SSA_MALFORMED where the reference panics (undecodable sig.x, src/batch.rs:67,104).  No torsion
- * check, like the reference.  Any n <= SSA_MAX_BATCH: above 2^24 signatures (SSA_MSM_SLICE) the batch runs slice after slice,
+ * check, like the reference.  Any n <= SSA_MAX_BATCH: above 2^23 signatures (SSA_MSM_SLICE) the batch runs slice after slice,
  * each reduced to its record like a shard, the records added up (src/batch.rs:98-129) -- bounded device memory. */
 int ssa_verify_batch_msm(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                          const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len,
@@ -302,7 +302,9 @@ int ssa_multi_verify_batch_msm(ssa_multi *m, const uint8_t *sigs, const uint8_t 
  * The same split as ssa_multi_verify_batch_msm, with the exchange left to the caller ("in the MSM
  * form, one point addition per shard + one compare", src/batch.rs:98-129): every rank reduces ITS shard to one
  * record of SSA_MSM_PARTIAL_WORDS u64 --
- *     words 0..17  the shard's left-hand point  sum s_i R_i - sum (s_i h_i) P_i  (Jacobian X, Y, Z, canonical limbs)
+ *     words 0..17  the shard's left-hand point  sum s_i R_i - sum (s_i h_i) P_i  as X, Y, Z in canonical limbs; the
+ *                  library writes the canonical form -- affine (x, y, 1), or (0, 0, 0) for the identity -- so equal
+ *                  shards give equal bytes; ssa_msm_combine accepts any Jacobian representative
  *     words 18..21 sum s_i e_i mod q            word 22  1: the shard holds an input the reference panics on, else 0
  *     word 23      SSA_MSM_RECORD_MAGIC -- every record the library produces carries it, the empty shard's too
  * -- the ranks all-gather the records (24 words per rank: the only traffic), and ssa_msm_combine adds the k points

@@ -98,7 +98,7 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     }
     if (const char *ms = std::getenv("SSA_MSM_SLICE")) {       // signatures per slice of the MSM-form pipeline
         const size_t v = (size_t)std::strtoull(ms, nullptr, 10);
-        if (v >= 256 && v <= ((size_t)1 << 25)) ctx->msm_slice = v;
+        if (v >= 256 && v <= ((size_t)1 << 23)) ctx->msm_slice = v;
     }
     if (const char *pc = std::getenv("SSA_PIPELINE_CHUNKS")) {
         const int v = std::atoi(pc);

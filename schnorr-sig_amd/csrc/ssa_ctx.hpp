@@ -87,7 +87,7 @@ struct ssa_ctx {
     // Workspace bound: the per-lane kernels run over slices of at most lane_slice lanes (2 KB of table + 32 B of scalar
     // each: 2.1 GB at 2^20), the MSM-form pipeline over slices of at most msm_slice signatures whose records are
     // combined like the shards of a multi-GPU batch.  SSA_LANE_SLICE / SSA_MSM_SLICE override (tests force small ones).
-    size_t lane_slice = (size_t)1 << 20, msm_slice = (size_t)1 << 24;
+    size_t lane_slice = (size_t)1 << 20, msm_slice = (size_t)1 << 23;
     DevBuf msm_slice_recs;        // one 24-word record per MSM slice
     // signing (ssa_sign.hip): the 4-bit comb table of the constant-time signer (98 KB, built at the first use) and the
     // intermediates of the keyed (130-byte) output

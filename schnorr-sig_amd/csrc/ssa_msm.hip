@@ -6,14 +6,26 @@
 // with R_i decompressed from sig.x (src/batch.rs:104), h_i = hash_message scalars (:64-73), s_i the
 // random coefficients (:75-78).  The 2n-point multi-scalar multiplication is a bucket method laid out
 // for the GPU:
-//   1. msm_k_prepare   per signature: decompress R, form the points R_i, -P_i and the scalars
-//                      a_i = s_i, b_i = s_i h_i mod q, and block-reduce s_i e_i mod q
-//   2. msm_k_digits    (window, digit) sort keys for every point; hipCUB radix sort groups the point
-//                      indices of each bucket; msm_k_bounds finds the bucket extents
+//   1. msm_k_prepare   per signature: decompress R, form the points R_i, -P_i and the scalars a_i = s_i,
+//                      b_i = s_i h_i mod q -- written as SIGNED c-bit digits (|d| <= 2^(c-1): half the buckets
+//                      of the unsigned form, a negative digit adds the negated point) --, block-reduce s_i e_i
+//   2. grouping the (point, window) items by bucket -- the library's own two-level counting sort (round 4; hipCUB's
+//      radix sort and its ~40 small launches are gone): the items of one window are consecutive, so a tile of 4096
+//      items belongs to ONE window:
+//        msm_k_hist     per tile (16384 items): LDS histogram of the HIGH 8 bits of the bucket number
+//        msm_k_rowsum / msm_k_rowscan   exclusive scan of the (bin, tile) counts -> every tile's write positions
+//        msm_k_scatter  per tile: items -> their (window, high-bits) group, ranks by LDS atomics (order inside a
+//                       bucket means nothing to a sum: no stable pass is needed)
+//        msm_k_group    per group (~4096 items, 128 buckets): LDS counting sort by the low 7 bits; the buckets'
+//                       extents fall out of it (no keys are stored, no bounds pass, no global atomic anywhere)
+//        msm_k_sizes / msm_k_size_ranks / msm_k_order   the buckets in global order of size, largest first: the 64
+//                       buckets of a wave hold the same number of points (sizes are Poisson-distributed and a wave
+//                       waits for its largest) and the launch ends on its shortest waves
 //   3. msm_k_buckets   ONE BUCKET PER LANE: a lane adds up the points of its bucket with mixed
 //                      additions (every exceptional case handled: equal public keys land in one bucket)
-//   4. msm_k_chunks    running-sum trick on chunks of 8 buckets (short chains, 2^17 lanes);
-//                      msm_k_tree (pairwise, x13) sums the chunk sums of a window; msm_k_finish is ONE cooperative
+//   4. msm_k_chunks    running-sum trick on chunks of 8 buckets (short chains, 2^16 lanes);
+//                      msm_k_tree sums the chunk sums of a window 16 at a time, one cooperating wave per sum
+//                      (three launches); msm_k_finish is ONE cooperative
 //                      block: wave 0 combines the windows by Horner's rule (the only long sequential chain
 //                      of the method, ~240 doublings, wave-cooperative Fp6 arithmetic), wave 1 computes
 //                      [lin]G from the comb table meanwhile; then the x coordinates are compared
@@ -21,27 +33,65 @@
 #define SSA_NO_KERNELS 1
 #include "ssa_ctx.hpp"
 
-#include <hipcub/hipcub.hpp>
-
 #include <sys/random.h>
 
 namespace ssa {
 
 constexpr int MSM_CHUNK = 8;   // buckets per lane in the running-sum pass (short chains, many lanes)
-constexpr u32 MSM_TREE_GROUP = 2;   // pairwise: the tree is latency-bound (lone waves), 13 levels of ONE addition beat 5 of eight
+constexpr u32 MSM_TREE_GROUP = 16;  // one cooperating wave sums 16 chunk sums (15 additions of ~2.2 us): 4096 -> 256 -> 16 -> 1
 
 struct MsmShape {
     u32 c;        // window bits
-    u32 windows;  // ceil(255 / c)
-    u32 buckets;  // 2^c
+    u32 windows;  // ceil(255 / c) (+ 0: the top window of a 255-bit scalar has c - 1 bits, the last carry fits)
+    u32 buckets;  // per window: 2^(c-1), for |digit| = 1 .. 2^(c-1) (signed digits; digit 0 contributes nothing)
     u32 chunks;   // per window
 };
 
+constexpr u32 MSM_TILE = 16384;         // items per tile of the grouping passes (256 threads x 64): a tile writes runs of
+                                        // ~64 items (256 B) per group
+constexpr u32 MSM_HI_BINS = 256;        // groups per window: the bucket number's bits above the low 7
+constexpr u32 MSM_LO_BITS = 7, MSM_LO_BINS = 1u << MSM_LO_BITS;
+constexpr u32 MSM_MAX_WINDOWS = 32;
+
+// the (point, window) items in window-major order: window j holds the P points (n .. 2n-1) always and the R points
+// (0 .. n-1) while j < wa (a coefficient of `coeff_bytes` bytes reaches only its lowest wa windows)
+struct MsmItems {
+    u32 n, wa, windows;
+    u32 tile0[MSM_MAX_WINDOWS + 1];     // first tile of window j (tiles never straddle two windows)
+    u32 base[MSM_MAX_WINDOWS + 1];      // first position of window j's region in the item arrays
+};
+SSA_DEV u32 items_of_window(const MsmItems &it, u32 j) { return j < it.wa ? 2u * it.n : it.n; }
+// item k of window j -> point index
+SSA_DEV u32 item_point(const MsmItems &it, u32 j, u32 k) { return j < it.wa ? k : it.n + k; }
+
 SSA_DEV u32 sc_window(const u64 *__restrict__ k, u32 bit, u32 c) {
     const u32 wi = bit >> 6, sh = bit & 63u;
+    if (wi > 3) return 0u;
     u64 v = k[wi] >> sh;
     if (sh + c > 64 && wi < 3) v |= k[wi + 1] << (64 - sh);
     return (u32)(v & ((1ull << c) - 1ull));
+}
+
+// Signed c-bit digits, window-major: digits[j * npts + pt] in [-2^(c-1), 2^(c-1) - 1] -- every window read as a
+// two's-complement number with the carry of the window below:
+//   raw = window_j(k) + carry;  raw >= 2^(c-1): digit = raw - 2^c, carry 1.
+// Returns the carry out of the LAST window: the digits represent  k - carry_out * 2^(windows * c).  A scalar mod q
+// (< 2^255: its top window has c - 1 bits and a value below 2^(c-1) - 1) never carries out; a narrow coefficient that
+// fills its windows to the last bit may (see msm_k_prepare: the coefficient then IS the value its digits represent).
+SSA_DEV u32 write_signed_digits(const sc256 &k, u32 c, u32 windows, short *__restrict__ digits, size_t npts, size_t pt) {
+    const int half = 1 << (c - 1);
+    int carry = 0;
+#pragma unroll 1
+    for (u32 j = 0; j < windows; j++) {
+        int raw = (int)sc_window(k.w, j * c, c) + carry;
+        carry = 0;
+        if (raw >= half) {
+            raw -= 2 * half;
+            carry = 1;
+        }
+        digits[(size_t)j * npts + pt] = (short)raw;
+    }
+    return (u32)carry;
 }
 
 SSA_DEV void st_aff_row(u64 *__restrict__ row, const aff &p) {
@@ -53,8 +103,8 @@ SSA_DEV void st_aff_row(u64 *__restrict__ row, const aff &p) {
 __global__ void __launch_bounds__(256)
 msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 *__restrict__ pk_inf,
               const u64 *__restrict__ h_in,
-              const u8 *__restrict__ coeffs, u32 coeff_bytes, size_t n, u64 *__restrict__ points,
-              u64 *__restrict__ scalars, u64 *__restrict__ partials, u32 *__restrict__ malformed) {
+              const u8 *__restrict__ coeffs, u32 coeff_bytes, size_t n, MsmShape shp, u32 wa, u64 *__restrict__ points,
+              short *__restrict__ digits, u64 *__restrict__ partials, u32 *__restrict__ malformed) {
     __shared__ u64 red[256 * 4];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     sc256 se;
@@ -92,7 +142,32 @@ msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 
         for (int k = 0; k < 4; k++) s.w[k] = 0;
         const u8 *cp = coeffs + (size_t)coeff_bytes * i;
         for (u32 b = 0; b < coeff_bytes; b++) s.w[b >> 3] |= (u64)cp[b] << (8 * (b & 7u));
-        s = sc_reduce256(s);                                           // Scalar::random, :75-78
+        // R_i carries the coefficient itself.  A 32-byte coefficient is taken mod q (Scalar::random, :75-78) and recoded
+        // over all the windows.  A narrower one is recoded over ITS OWN wa windows only -- a carry window on top would
+        // hold the digit 1 for half of the points: one enormous bucket -- so when its signed digits carry out of the
+        // last window (a coefficient that fills its windows to the top bit, about half of the 128-bit ones) they
+        // represent  raw - 2^(wa c), and THAT value is the coefficient: it multiplies R_i (through the digits), h_i and
+        // e_i (through s below) alike, so the equation is the reference's with another, equally random, coefficient.
+        if (coeff_bytes >= 32u) {
+            s = sc_reduce256(s);
+            (void)write_signed_digits(s, shp.c, wa, digits, 2 * n, i);
+        } else if (write_signed_digits(s, shp.c, wa, digits, 2 * n, i)) {      // -(2^(wa c) - raw) mod q
+            const u32 bits = wa * shp.c;        // (< 256: a narrow coefficient has fewer windows than a scalar)
+            sc256 s_abs;
+            u64 borrow = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 lo_bit = 64u * (u32)k;
+                const u64 pw = (bits >= lo_bit && bits < lo_bit + 64u) ? 1ull << (bits - lo_bit) : 0ull;
+                const u64 d = pw - s.w[k];
+                const u64 b1 = pw < s.w[k];
+                const u64 d2 = d - borrow;
+                const u64 b2 = d < borrow;
+                s_abs.w[k] = d2;
+                borrow = b1 | b2;
+            }
+            s = sc_neg_mod(s_abs);
+        }
         sc256 h;
 #pragma unroll
         for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
@@ -101,11 +176,7 @@ msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 
         P.y = f6_canon(f6_neg(P.y));                                   // k.0.neg(), :106
         st_aff_row(points + 12 * i, R);
         st_aff_row(points + 12 * (n + i), P);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            scalars[4 * i + k] = s.w[k];
-            scalars[4 * (n + i) + k] = sh.w[k];
-        }
+        (void)write_signed_digits(sh, shp.c, shp.windows, digits, 2 * n, n + i);
     }
     // block reduction of s_i e_i mod q
 #pragma unroll
@@ -131,92 +202,242 @@ msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 
     }
 }
 
-// ---- 2. sort keys ------------------------------------------------------------------------------
-// The first n points (the R_i) carry the coefficients s_i themselves: with coefficients of `coeff_bytes` bytes only
-// their lowest wa windows can be non-zero, and the sort is spared the rest (a quarter of the items for the 128-bit
-// coefficients the library draws); the other n points (the P_i) carry s_i h_i mod q and occupy every window.
-__global__ void msm_k_digits(const u64 *__restrict__ scalars, size_t n, u32 wa, MsmShape sh,
-                             u32 *__restrict__ keys, u32 *__restrict__ vals) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t first = n * wa;
-    if (t >= first + n * sh.windows) return;
-    u32 j;
-    size_t i;
-    if (t < first) {
-        j = (u32)(t / n);
-        i = t - (size_t)j * n;
-    } else {
-        const size_t u = t - first;
-        j = (u32)(u / n);
-        i = n + (u - (size_t)j * n);
-    }
-    const u32 d = sc_window(scalars + 4 * i, j * sh.c, sh.c);
-    keys[t] = j * sh.buckets + d;
-    vals[t] = (u32)i;
+// ---- 2. grouping the items by bucket ------------------------------------------------------------------
+// bucket number of a digit: |d| - 1 in [0, 2^(c-1)); hi = its bits above the low 7 (the group), lo = the low 7
+SSA_DEV bool tile_of_block(const MsmItems &it, u32 blk, u32 &j, u32 &k0, u32 &cnt) {
+    j = 0;
+#pragma unroll 1
+    while (j + 1 < it.windows && blk >= it.tile0[j + 1]) j++;
+    const u32 items = items_of_window(it, j);
+    k0 = (blk - it.tile0[j]) * MSM_TILE;
+    if (k0 >= items) return false;
+    cnt = items - k0 < MSM_TILE ? items - k0 : MSM_TILE;
+    return true;
 }
 
-// bounds[2*key] = first position, bounds[2*key+1] = one past the last (both 0 for empty buckets)
-__global__ void msm_k_bounds(const u32 *__restrict__ keys, size_t total, u32 *__restrict__ bounds) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const u32 k = keys[t];
-    if (t == 0 || keys[t - 1] != k) bounds[2 * (size_t)k] = (u32)t;
-    if (t + 1 == total || keys[t + 1] != k) bounds[2 * (size_t)k + 1] = (u32)(t + 1);
+// tile_hist[(j * 256 + bin) * tmax + tile] = items of this tile whose bucket lies in group `bin`
+__global__ void __launch_bounds__(256)
+msm_k_hist(const short *__restrict__ digits, MsmItems it, u32 tmax, u32 *__restrict__ tile_hist) {
+    __shared__ u32 h[MSM_HI_BINS];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    u32 j, k0, cnt;
+    if (!tile_of_block(it, blockIdx.x, j, k0, cnt)) return;        // (block-uniform)
+    const short *dj = digits + (size_t)j * (2u * (size_t)it.n);
+    for (u32 k = threadIdx.x; k < cnt; k += 256u) {
+        const int d = dj[item_point(it, j, k0 + k)];
+        if (d != 0) atomicAdd(&h[(u32)((d < 0 ? -d : d) - 1) >> MSM_LO_BITS], 1u);
+    }
+    __syncthreads();
+    tile_hist[((size_t)j * MSM_HI_BINS + threadIdx.x) * tmax + (blockIdx.x - it.tile0[j])] = h[threadIdx.x];
+}
+
+// Exclusive scan of a window's (bin, tile) counts in bin-major order, in place, in two steps:
+//   msm_k_rowsum  one wave per (window, bin) row: the row's total
+//   msm_k_rowscan one block per row: base = the window's region + the totals of the bins before it, then the row's
+//                 exclusive scan in place -> the position at which tile `tile` writes its first item of group `bin`;
+//                 gstart[j * 257 + bin] = first position of the group, gstart[j * 257 + 256] = one past the window's last
+__global__ void __launch_bounds__(64)
+msm_k_rowsum(MsmItems it, u32 tmax, const u32 *__restrict__ tile_hist, u32 *__restrict__ rowsum) {
+    const u32 row = blockIdx.x, j = row / MSM_HI_BINS;
+    const u32 tiles = it.tile0[j + 1] - it.tile0[j];
+    const u32 *th = tile_hist + (size_t)row * tmax;
+    u32 sum = 0;
+    for (u32 t = threadIdx.x; t < tiles; t += 64u) sum += th[t];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if (threadIdx.x == 0) rowsum[row] = sum;
+}
+
+__global__ void __launch_bounds__(256)
+msm_k_rowscan(MsmItems it, u32 tmax, const u32 *__restrict__ rowsum, u32 *__restrict__ tile_hist,
+              u32 *__restrict__ gstart) {
+    __shared__ u32 sh[256];
+    const u32 row = blockIdx.x, j = row / MSM_HI_BINS, bin = row % MSM_HI_BINS;
+    const u32 tiles = it.tile0[j + 1] - it.tile0[j];
+    // totals of the bins before this one (and of all of them, for the sentinel)
+    const u32 mine = rowsum[j * MSM_HI_BINS + threadIdx.x];
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (u32 off = 1; off < 256u; off <<= 1) {
+        const u32 v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const u32 before = bin ? sh[bin - 1] : 0u, all = sh[255];
+    __syncthreads();
+    u32 run = it.base[j] + before;
+    if (threadIdx.x == 0) {
+        gstart[j * (MSM_HI_BINS + 1) + bin] = run;
+        if (bin == MSM_HI_BINS - 1) gstart[j * (MSM_HI_BINS + 1) + MSM_HI_BINS] = it.base[j] + all;
+    }
+    u32 *th = tile_hist + (size_t)row * tmax;
+    for (u32 t0 = 0; t0 < tiles; t0 += 256u) {           // the row in pieces of 256 tiles, the running total carried
+        const u32 t = t0 + threadIdx.x;
+        const u32 c = t < tiles ? th[t] : 0u;
+        sh[threadIdx.x] = c;
+        __syncthreads();
+        for (u32 off = 1; off < 256u; off <<= 1) {
+            const u32 v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (t < tiles) th[t] = run + sh[threadIdx.x] - c;
+        const u32 piece = sh[255];
+        __syncthreads();
+        run += piece;
+    }
+}
+
+// items -> their group, ONE word per item: v1[pos] = point index (24 bits: 2n <= 2^24 per slice) | low 7 bits of the
+// bucket number << 24 | sign << 31
+__global__ void __launch_bounds__(256)
+msm_k_scatter(const short *__restrict__ digits, MsmItems it, u32 tmax, const u32 *__restrict__ tile_hist,
+              u32 *__restrict__ v1) {
+    __shared__ u32 cur[MSM_HI_BINS];
+    u32 j, k0, cnt;
+    if (!tile_of_block(it, blockIdx.x, j, k0, cnt)) return;
+    cur[threadIdx.x] = tile_hist[((size_t)j * MSM_HI_BINS + threadIdx.x) * tmax + (blockIdx.x - it.tile0[j])];
+    __syncthreads();
+    const short *dj = digits + (size_t)j * (2u * (size_t)it.n);
+    for (u32 k = threadIdx.x; k < cnt; k += 256u) {
+        const u32 pt = item_point(it, j, k0 + k);
+        const int d = dj[pt];
+        if (d != 0) {
+            const u32 b = (u32)((d < 0 ? -d : d) - 1);
+            const u32 pos = atomicAdd(&cur[b >> MSM_LO_BITS], 1u);
+            v1[pos] = pt | ((b & (MSM_LO_BINS - 1u)) << 24) | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// one block per (window, group): counting sort of the group's items by the low 7 bits of their bucket number; the
+// 128 buckets' extents are the by-product: bstart[t], cnt[t] for t = j * buckets + group * 128 + lo
+__global__ void __launch_bounds__(256)
+msm_k_group(const u32 *__restrict__ gstart, const u32 *__restrict__ v1, MsmShape sh, u32 *__restrict__ v2,
+            u32 *__restrict__ bstart, u32 *__restrict__ cnt) {
+    __shared__ u32 h[MSM_LO_BINS], pre[MSM_LO_BINS];
+    const u32 j = blockIdx.x / MSM_HI_BINS, bin = blockIdx.x % MSM_HI_BINS;
+    if (bin * MSM_LO_BINS >= sh.buckets) return;                    // (narrow windows have fewer groups)
+    const u32 gs = gstart[j * (MSM_HI_BINS + 1) + bin], ge = gstart[j * (MSM_HI_BINS + 1) + bin + 1];
+    if (threadIdx.x < MSM_LO_BINS) h[threadIdx.x] = 0u;
+    __syncthreads();
+    for (u32 p = gs + threadIdx.x; p < ge; p += 256u) atomicAdd(&h[(v1[p] >> 24) & (MSM_LO_BINS - 1u)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64u) {          // exclusive scan of the 128 counts on one wave: two per lane
+        const u32 a = h[2u * threadIdx.x], b = h[2u * threadIdx.x + 1u];
+        u32 incl = a + b;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 v = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += v;
+        }
+        pre[2u * threadIdx.x] = incl - a - b;
+        pre[2u * threadIdx.x + 1u] = incl - b;
+    }
+    __syncthreads();
+    if (threadIdx.x < MSM_LO_BINS && bin * MSM_LO_BINS + threadIdx.x < sh.buckets) {
+        const size_t t = (size_t)j * sh.buckets + bin * MSM_LO_BINS + threadIdx.x;
+        bstart[t] = gs + pre[threadIdx.x];
+        cnt[t] = h[threadIdx.x];
+    }
+    __syncthreads();
+    for (u32 p = gs + threadIdx.x; p < ge; p += 256u) {
+        const u32 v = v1[p];
+        v2[gs + atomicAdd(&pre[(v >> 24) & (MSM_LO_BINS - 1u)], 1u)] = v & 0x80ffffffu;
+    }
+}
+
+// Bucket sizes are Poisson-distributed (mean ~48 at n = 2^20) and a wave waits for its largest bucket: the lanes take
+// the buckets in GLOBAL order of size, largest first (sizes clamped at 1023) -- the 64 buckets of a wave hold the same
+// number of points, and the long waves start first, so the launch ends on its shortest ones (with four waves per
+// slot at 2^20 signatures a long wave started late would idle most of the chip: measured 3.5 ms against 3.0 for the
+// same additions when the order was only local).  Counting sort in three small launches; the only global atomics are
+// one per (block, size class present in the block): ~60 per block.
+__global__ void __launch_bounds__(1024)
+msm_k_sizes(const u32 *__restrict__ cnt, u32 nb, u32 *__restrict__ ghist) {
+    __shared__ u32 h[1024];
+    const u32 t = blockIdx.x * 1024u + threadIdx.x;
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    if (t < nb) atomicAdd(&h[cnt[t] < 1023u ? cnt[t] : 1023u], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
+}
+// gcur[c] = first rank of size class c when the classes are laid out from 1023 down to 0
+__global__ void __launch_bounds__(1024)
+msm_k_size_ranks(const u32 *__restrict__ ghist, u32 *__restrict__ gcur) {
+    __shared__ u32 h[1024];
+    const u32 mine = ghist[1023u - threadIdx.x];
+    h[threadIdx.x] = mine;
+    __syncthreads();
+    for (u32 off = 1; off < 1024u; off <<= 1) {
+        const u32 v = threadIdx.x >= off ? h[threadIdx.x - off] : 0u;
+        __syncthreads();
+        h[threadIdx.x] += v;
+        __syncthreads();
+    }
+    gcur[1023u - threadIdx.x] = h[threadIdx.x] - mine;
+}
+__global__ void __launch_bounds__(1024)
+msm_k_order(const u32 *__restrict__ cnt, u32 nb, u32 *__restrict__ gcur, u32 *__restrict__ order) {
+    __shared__ u32 h[1024], base[1024];
+    const u32 t = blockIdx.x * 1024u + threadIdx.x;
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const u32 c = t < nb ? (cnt[t] < 1023u ? cnt[t] : 1023u) : 0u;
+    if (t < nb) atomicAdd(&h[c], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&gcur[threadIdx.x], h[threadIdx.x]);   // this block's run of the class
+    __syncthreads();
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    if (t < nb) order[base[c] + atomicAdd(&h[c], 1u)] = t;
 }
 
 // ---- 3. one bucket per lane ---------------------------------------------------------------------
-// Bucket sizes are Poisson-distributed (mean 16 or 32 at n = 2^20) and a wave waits for its largest bucket:
-// the buckets are handed to the lanes in order of size (a 1 M-item radix sort, ~0.2 ms), so that the 64
-// buckets of a wave hold the same number of points.
-__global__ void msm_k_counts(const u32 *__restrict__ bounds, MsmShape sh, u32 *__restrict__ cnt,
-                             u32 *__restrict__ ids) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)sh.windows * sh.buckets) return;
-    cnt[t] = (t & (sh.buckets - 1)) != 0 ? bounds[2 * t + 1] - bounds[2 * t] : 0u;   // digit 0 contributes nothing
-    ids[t] = (u32)t;
-}
-
 __global__ void __launch_bounds__(256, 2)
-msm_k_buckets(const u64 *__restrict__ points, const u32 *__restrict__ vals, const u32 *__restrict__ bounds,
-              const u32 *__restrict__ order, MsmShape sh, u64 *__restrict__ bsum) {
+msm_k_buckets(const u64 *__restrict__ points, const u32 *__restrict__ vals, const u32 *__restrict__ bstart,
+              const u32 *__restrict__ cnt, const u32 *__restrict__ order, size_t nb, u64 *__restrict__ bsum) {
     const size_t lane_id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nb = (size_t)sh.windows * sh.buckets;
     if (lane_id >= nb) return;
     const size_t t = order[lane_id];
     jac acc = jac_identity();
-    if ((t & (sh.buckets - 1)) != 0) {
-        const u32 lo = bounds[2 * t], hi = bounds[2 * t + 1];
+    const u32 lo = bstart[t], hi = lo + cnt[t];
 #pragma unroll 1
-        for (u32 p = lo; p < hi; p++) {
-            const aff q = ld_aff(points + 12 * (size_t)vals[p]);
-            acc = jac_madd_fast(acc, q);      // asm block; identity / equal points fall back to the exact addition
-        }
+    for (u32 p = lo; p < hi; p++) {
+        const u32 item = vals[p];
+        aff q = ld_aff(points + 12 * (size_t)(item & 0x7fffffffu));
+        if (item >> 31) q.y = f6_neg(q.y);                // a negative digit adds the negated point ((0, 0) stays (0, 0))
+        acc = jac_madd_fast(acc, q);      // asm block; identity / equal points fall back to the exact addition
     }
     st_jac(bsum + 18 * t, acc);
 }
 
 // ---- 4. bucket reduction ------------------------------------------------------------------------
-// chunk of MSM_CHUNK buckets [v0, v0 + L): sum_v v B_v = sum_v (v - v0 + 1) B_v + (v0 - 1) sum_v B_v
+// chunk of MSM_CHUNK buckets [k0, k0 + L) of a window, bucket k weighing k + 1 (|digit|):
+//   sum_k (k + 1) B_k = sum_k (k - k0 + 1) B_k + k0 sum_k B_k
 __global__ void __launch_bounds__(256, 2)
 msm_k_chunks(const u64 *__restrict__ bsum, MsmShape sh, u64 *__restrict__ chunk_out) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)sh.windows * sh.chunks) return;
     const u32 j = (u32)(t / sh.chunks), ch = (u32)(t % sh.chunks);
     const u32 len = sh.buckets < (u32)MSM_CHUNK ? sh.buckets : (u32)MSM_CHUNK;
-    const u32 v0 = ch * len;
+    const u32 k0 = ch * len;
     // the top bucket opens both sums (two additions to the identity saved per chunk)
-    jac running = ld_jac(bsum + 18 * ((size_t)j * sh.buckets + (v0 + len - 1))), total = running;
+    jac running = ld_jac(bsum + 18 * ((size_t)j * sh.buckets + (k0 + len - 1))), total = running;
 #pragma unroll 1
-    for (int v = (int)(v0 + len) - 2; v >= (int)v0; v--) {
-        if (v == 0) break;
-        const jac b = ld_jac(bsum + 18 * ((size_t)j * sh.buckets + (u32)v));
+    for (int k = (int)(k0 + len) - 2; k >= (int)k0; k--) {
+        const jac b = ld_jac(bsum + 18 * ((size_t)j * sh.buckets + (u32)k));
         running = jac_add(running, b);
         total = jac_add(total, running);
     }
-    // + [v0 - 1] running (v0 >= 1 here unless this is the first chunk, where the weight offset is 0): double-and-add from
-    // the top set bit of the weight, the doublings through the ladder's generated statement
-    if (v0 > 1) {
-        const u32 m = v0 - 1;
+    // + [k0] running: double-and-add from the top set bit of the weight, the doublings through the ladder's
+    // generated statement
+    if (k0 > 0) {
+        const u32 m = k0;
         jac acc = running;
 #pragma unroll 1
         for (int bit = 30 - __builtin_clz(m); bit >= 0; bit--) {
@@ -228,18 +449,39 @@ msm_k_chunks(const u64 *__restrict__ bsum, MsmShape sh, u64 *__restrict__ chunk_
     st_jac(chunk_out + 18 * t, total);
 }
 
-// tree step: out[j][g] = sum of `group` consecutive points of window j's `count` inputs
-__global__ void __launch_bounds__(64, 2)
+// tree step: out[j][g] = sum of `group` consecutive points of window j's `count` inputs.  ONE WAVE per output, the
+// general additions on the wave-cooperative arithmetic (ssa_coop.hpp: ~2.2 us per addition, where a lone lane takes ~15):
+// three launches of 16-way sums replace round 3's twelve pairwise ones (0.20 -> 0.1 ms).
+__global__ void __launch_bounds__(64)
 msm_k_tree(const u64 *__restrict__ in, u32 windows, u32 count, u32 group, u64 *__restrict__ out) {
+    __shared__ CoopLds L;
+    const u32 lane = threadIdx.x;
     const u32 groups = (count + group - 1) / group;
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = blockIdx.x;
     if (t >= windows * groups) return;
     const u32 j = t / groups, g = t % groups;
-    const u32 lo = g * group, hi = (lo + group < count) ? lo + group : count;
-    jac acc = ld_jac(in + 18 * ((size_t)j * count + lo));        // (lo < hi always: groups = ceil(count / group))
+    const u32 lo = g * group, hi = (lo + group < count) ? lo + group : count;    // (lo < hi: groups = ceil(count / group))
+    int tt[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) tt[k] = 7 + k;
+    // accumulator 0..3 (X, Y, Z, W = Z^4), addend 4..6
+    auto load = [&](int s0, u32 k) {
+        if (lane < 36) {
+            const u32 v = lane / 12u, c = lane % 12u;
+            const u64 w = in[18 * ((size_t)j * count + k) + 6u * v + c % 6u];
+            L.slot[s0 + (int)v][c] = c < 6 ? w : fp_mul_small(w, 7u);
+        }
+        coop_sync();
+    };
+    load(0, lo);
+    coop_mul(L, 3, 2, 2, lane, 0);
+    coop_mul(L, 3, 3, 3, lane, 0);
 #pragma unroll 1
-    for (u32 k = lo + 1; k < hi; k++) acc = jac_add(acc, ld_jac(in + 18 * ((size_t)j * count + k)));
-    st_jac(out + 18 * (size_t)t, acc);
+    for (u32 k = lo + 1; k < hi; k++) {
+        load(4, k);
+        coop_jac_add(L, 0, 4, tt, lane, 0);
+    }
+    if (lane < 18) out[18 * (size_t)t + lane] = fp_canon(L.slot[(int)(lane / 6u)][lane % 6u]);
 }
 
 // ---- coefficients ---------------------------------------------------------------------------------
@@ -384,7 +626,25 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
     }
     __syncthreads();
     if (partial_out) {
-        if (ws == 0 && lane < 18) partial_out[lane] = fp_canon(L.slot[(int)(lane / 6u)][lane % 6u]);
+        // The record carries the point in its CANONICAL form: affine (x, y, 1), or (0, 0, 0) for the identity.  The
+        // grouping passes rank the items of a bucket by LDS atomics, so the order of the additions -- and with it
+        // the Jacobian representative -- differs from run to run; the point does not, and equal shards give equal
+        // bytes (records are compared, committed as fixtures and cross process boundaries).
+        if (ws == 0) {
+            const bool inf = coop_is_zero(L, 2, lane, ws);
+            if (!inf) {
+                coop_inv(L, 7, 2, 8, 9, 10, lane, ws);     // 1 / Z
+                coop_mul(L, 8, 7, 7, lane, ws);            // 1 / Z^2
+                coop_mul(L, 0, 0, 8, lane, ws);            // x
+                coop_mul(L, 8, 8, 7, lane, ws);            // 1 / Z^3
+                coop_mul(L, 1, 1, 8, lane, ws);            // y
+            }
+            if (lane < 18) {
+                const u32 v = lane / 6u, c = lane % 6u;
+                u64 w = v == 2 ? (c == 0 ? 1ull : 0ull) : fp_canon(L.slot[(int)v][c]);
+                partial_out[lane] = inf ? 0ull : w;
+            }
+        }
         if (threadIdx.x == 0) {
             partial_out[22] = 0;
             partial_out[23] = SSA_MSM_RECORD_MAGIC;
@@ -622,11 +882,12 @@ static MsmShape msm_shape(size_t n) {
     // Window width: 16 bits, or 8 for small batches.  Both divide 128 (library-drawn coefficients) and
     // leave a wide top window for 255-bit scalars (255 mod 16 = 15, 255 mod 8 = 7): a narrow partial
     // window would have a handful of digits and therefore a handful of enormous buckets (measured:
-    // c = 14 put n/4 points into single lanes and took 0.9 s at n = 2^18).
+    // c = 14 put n/4 points into single lanes and took 0.9 s at n = 2^18).  Signed digits (round 4): 2^(c-1)
+    // buckets per window, and the top window's c - 1 bits absorb the last carry.
     MsmShape sh;
     sh.c = n >= 4096 ? 16u : 8u;
     sh.windows = (255 + sh.c - 1) / sh.c;
-    sh.buckets = 1u << sh.c;
+    sh.buckets = 1u << (sh.c - 1);
     sh.chunks = sh.buckets <= (u32)MSM_CHUNK ? 1u : sh.buckets / (u32)MSM_CHUNK;
     return sh;
 }
@@ -767,7 +1028,7 @@ static int msm_run_one(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks
                        const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
                        const uint8_t *d_coeffs, uint32_t coeff_bytes, uint32_t *d_verdict_out, u64 *d_partial_out,
                        const u64 *d_h) {
-    if (n > (1ull << 25)) return SSA_ERR_ARG;   // 2n * 16 sort items must fit the sort's 32-bit positions
+    if (n > (1ull << 23)) return SSA_ERR_ARG;   // an item carries its point index in 24 bits: 2n <= 2^24 (msm_run slices)
     if (n == 0) {   // empty batch: Ok (src/batch.rs); an empty shard adds the identity and 0
         if (d_partial_out) {
             hipLaunchKernelGGL(msm_k_empty_record, dim3(1), dim3(64), 0, ctx->stream, d_partial_out);
@@ -786,36 +1047,40 @@ static int msm_run_one(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks
     if (n <= ctx->msm_small_max) return msm_run_small(ctx, d_sigs, d_pks, d_pk_inf, d_msgs, d_msg_off, msg_stride, msg_len, n,
                                                       d_coeffs, coeff_bytes, d_verdict_out, d_partial_out);
     const MsmShape sh = msm_shape(n);
-    // windows the coefficients themselves can reach (they are reduced mod q when they are as wide as q)
+    // windows the coefficients themselves can reach (32-byte ones are reduced mod q: all of them).  A narrower coefficient
+    // whose width is a whole number of windows is read as a TWO'S-COMPLEMENT integer (msm_k_prepare): its signed digits
+    // then need no carry window -- which would hold the digit 1 for half of the points, one enormous bucket -- and a
+    // random coefficient is as good signed as unsigned (the same value multiplies R_i, h_i and e_i).
     const u32 wa = coeff_bytes >= 32 ? sh.windows : (8u * coeff_bytes + sh.c - 1) / sh.c;
-    const size_t npts = 2 * n, total = n * wa + n * sh.windows, nb = (size_t)sh.windows * sh.buckets;
+    MsmItems it;
+    it.n = (u32)n;
+    it.wa = wa;
+    it.windows = sh.windows;
+    it.tile0[0] = it.base[0] = 0;
+    for (u32 j = 0; j < sh.windows; j++) {
+        const size_t items = j < wa ? 2 * n : n;
+        it.tile0[j + 1] = it.tile0[j] + (u32)((items + MSM_TILE - 1) / MSM_TILE);
+        it.base[j + 1] = it.base[j] + (u32)items;
+    }
+    const u32 n_tiles = it.tile0[sh.windows], tmax = (u32)((2 * n + MSM_TILE - 1) / MSM_TILE);
+    const size_t npts = 2 * n, total = it.base[sh.windows], nb = (size_t)sh.windows * sh.buckets;
     const unsigned n_blocks = grid_for(n, 256);
-    size_t sort_tmp = 0;
-    const int end_bit = 32 - __builtin_clz((unsigned)(nb - 1) | 1u);
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (const u32 *)nullptr, (u32 *)nullptr,
-                                           (const u32 *)nullptr, (u32 *)nullptr, (int)total, 0, end_bit,
-                                           ctx->stream) != hipSuccess)
-        return SSA_ERR_HIP;
-    size_t sort_tmp2 = 0;
-    const int cnt_bits = 33 - __builtin_clz((unsigned)npts | 1u);   // a bucket holds at most 2n points
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp2, (const u32 *)nullptr, (u32 *)nullptr,
-                                           (const u32 *)nullptr, (u32 *)nullptr, (int)nb, 0, cnt_bits > 32 ? 32 : cnt_bits,
-                                           ctx->stream) != hipSuccess)
-        return SSA_ERR_HIP;
-    if (sort_tmp2 > sort_tmp) sort_tmp = sort_tmp2;
-    if (ctx->msm_cnt.reserve(nb * 4) || ctx->msm_cnt2.reserve(nb * 4) || ctx->msm_ids.reserve(nb * 4) ||
-        ctx->msm_ids2.reserve(nb * 4))
-        return SSA_ERR_HIP;
-    if ((!d_h && ctx->ws_h.reserve(n * 32)) || ctx->msm_points.reserve(npts * 96) || ctx->msm_scalars.reserve(npts * 32) ||
-        ctx->msm_keys.reserve(total * 4) || ctx->msm_vals.reserve(total * 4) || ctx->msm_keys2.reserve(total * 4) ||
-        ctx->msm_vals2.reserve(total * 4) || ctx->msm_sort_tmp.reserve(sort_tmp + 16) ||
-        ctx->msm_bounds.reserve(nb * 8) || ctx->msm_buckets.reserve(nb * 144) ||
+    if ((!d_h && ctx->ws_h.reserve(n * 32)) || ctx->msm_points.reserve(npts * 96) ||
+        ctx->msm_scalars.reserve(npts * sh.windows * sizeof(short)) ||                 // signed digits, window-major
+        ctx->msm_keys.reserve((size_t)sh.windows * MSM_HI_BINS * tmax * 4) ||          // per-tile group counts / positions
+        ctx->msm_vals.reserve(total * 4) ||                                            // items by group: point | low bits | sign
+        ctx->msm_keys2.reserve((size_t)sh.windows * MSM_HI_BINS * 4) ||                // row totals of the scan
+        ctx->msm_ids.reserve(2048 * 4) ||                                              // size classes: counts, first ranks
+        ctx->msm_vals2.reserve(total * 4) ||                                           // items by bucket
+        ctx->msm_bounds.reserve(nb * 4) || ctx->msm_cnt.reserve(nb * 4) ||             // bucket extents
+        ctx->msm_ids2.reserve((nb + 1024) * 4) ||                                      // buckets in order of size
+        ctx->msm_cnt2.reserve((size_t)sh.windows * (MSM_HI_BINS + 1) * 4) ||           // group extents
+        ctx->msm_buckets.reserve(nb * 144) ||
         ctx->msm_chunks.reserve((size_t)sh.windows * sh.chunks * 144) ||
         ctx->msm_windows.reserve((size_t)sh.windows * sh.chunks * 144) ||
         ctx->msm_partials.reserve((size_t)n_blocks * 32) || ctx->msm_flags.reserve(64))
         return SSA_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->msm_bounds.p, 0, nb * 8, ctx->stream));
     // challenge scalars h_i with the kernel of the per-lane path
     if (!d_h) {
         if (int rc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
@@ -823,29 +1088,35 @@ static int msm_run_one(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks
     }
     int rc = timed_launch(ctx, "msm_k_prepare", [&] {
         hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, ctx->stream, d_sigs, d_pks, d_pk_inf,
-                           d_h, d_coeffs, coeff_bytes, n, (u64 *)ctx->msm_points.p,
-                           (u64 *)ctx->msm_scalars.p, (u64 *)ctx->msm_partials.p, (u32 *)ctx->msm_flags.p);
+                           d_h, d_coeffs, coeff_bytes, n, sh, wa, (u64 *)ctx->msm_points.p,
+                           (short *)ctx->msm_scalars.p, (u64 *)ctx->msm_partials.p, (u32 *)ctx->msm_flags.p);
     });
     if (rc) return rc;
     rc = timed_launch(ctx, "msm_sort", [&] {
-        hipLaunchKernelGGL(msm_k_digits, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream,
-                           (const u64 *)ctx->msm_scalars.p, n, wa, sh, (u32 *)ctx->msm_keys.p, (u32 *)ctx->msm_vals.p);
-        (void)hipcub::DeviceRadixSort::SortPairs(ctx->msm_sort_tmp.p, sort_tmp, (const u32 *)ctx->msm_keys.p,
-                                                 (u32 *)ctx->msm_keys2.p, (const u32 *)ctx->msm_vals.p,
-                                                 (u32 *)ctx->msm_vals2.p, (int)total, 0, end_bit, ctx->stream);
-        hipLaunchKernelGGL(msm_k_bounds, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream,
-                           (const u32 *)ctx->msm_keys2.p, total, (u32 *)ctx->msm_bounds.p);
+        hipLaunchKernelGGL(msm_k_hist, dim3(n_tiles), dim3(256), 0, ctx->stream, (const short *)ctx->msm_scalars.p, it, tmax,
+                           (u32 *)ctx->msm_keys.p);
+        hipLaunchKernelGGL(msm_k_rowsum, dim3(sh.windows * MSM_HI_BINS), dim3(64), 0, ctx->stream, it, tmax,
+                           (const u32 *)ctx->msm_keys.p, (u32 *)ctx->msm_keys2.p);
+        hipLaunchKernelGGL(msm_k_rowscan, dim3(sh.windows * MSM_HI_BINS), dim3(256), 0, ctx->stream, it, tmax,
+                           (const u32 *)ctx->msm_keys2.p, (u32 *)ctx->msm_keys.p, (u32 *)ctx->msm_cnt2.p);
+        hipLaunchKernelGGL(msm_k_scatter, dim3(n_tiles), dim3(256), 0, ctx->stream, (const short *)ctx->msm_scalars.p, it,
+                           tmax, (const u32 *)ctx->msm_keys.p, (u32 *)ctx->msm_vals.p);
+        hipLaunchKernelGGL(msm_k_group, dim3(sh.windows * MSM_HI_BINS), dim3(256), 0, ctx->stream,
+                           (const u32 *)ctx->msm_cnt2.p, (const u32 *)ctx->msm_vals.p, sh, (u32 *)ctx->msm_vals2.p,
+                           (u32 *)ctx->msm_bounds.p, (u32 *)ctx->msm_cnt.p);
     });
     if (rc) return rc;
     rc = timed_launch(ctx, "msm_k_buckets", [&] {
-        hipLaunchKernelGGL(msm_k_counts, dim3(grid_for(nb, 256)), dim3(256), 0, ctx->stream,
-                           (const u32 *)ctx->msm_bounds.p, sh, (u32 *)ctx->msm_cnt.p, (u32 *)ctx->msm_ids.p);
-        (void)hipcub::DeviceRadixSort::SortPairs(ctx->msm_sort_tmp.p, sort_tmp2, (const u32 *)ctx->msm_cnt.p,
-                                                 (u32 *)ctx->msm_cnt2.p, (const u32 *)ctx->msm_ids.p,
-                                                 (u32 *)ctx->msm_ids2.p, (int)nb, 0, cnt_bits > 32 ? 32 : cnt_bits, ctx->stream);
+        u32 *ghist = (u32 *)ctx->msm_ids.p, *gcur = ghist + 1024;
+        (void)hipMemsetAsync(ghist, 0, 1024 * 4, ctx->stream);
+        hipLaunchKernelGGL(msm_k_sizes, dim3(grid_for(nb, 1024)), dim3(1024), 0, ctx->stream, (const u32 *)ctx->msm_cnt.p,
+                           (u32)nb, ghist);
+        hipLaunchKernelGGL(msm_k_size_ranks, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)ghist, gcur);
+        hipLaunchKernelGGL(msm_k_order, dim3(grid_for(nb, 1024)), dim3(1024), 0, ctx->stream, (const u32 *)ctx->msm_cnt.p,
+                           (u32)nb, gcur, (u32 *)ctx->msm_ids2.p);
         hipLaunchKernelGGL(msm_k_buckets, dim3(grid_for(nb, 256)), dim3(256), 0, ctx->stream,
                            (const u64 *)ctx->msm_points.p, (const u32 *)ctx->msm_vals2.p,
-                           (const u32 *)ctx->msm_bounds.p, (const u32 *)ctx->msm_ids2.p, sh,
+                           (const u32 *)ctx->msm_bounds.p, (const u32 *)ctx->msm_cnt.p, (const u32 *)ctx->msm_ids2.p, nb,
                            (u64 *)ctx->msm_buckets.p);
     });
     if (rc) return rc;
@@ -858,7 +1129,7 @@ static int msm_run_one(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks
         u32 count = sh.chunks;
         while (count > 1) {
             const u32 groups = (count + MSM_TREE_GROUP - 1) / MSM_TREE_GROUP;
-            hipLaunchKernelGGL(msm_k_tree, dim3(grid_for((size_t)sh.windows * groups, 64)), dim3(64), 0, ctx->stream,
+            hipLaunchKernelGGL(msm_k_tree, dim3(sh.windows * groups), dim3(64), 0, ctx->stream,
                                (const u64 *)ping, sh.windows, count, MSM_TREE_GROUP, pong);
             u64 *tmp = ping;
             ping = pong;
