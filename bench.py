@@ -58,10 +58,11 @@ W_VERIFY_KEYED_COMB = (32 + 16) * W_MADD + F6_MUL + F6_SQR   # per-key comb: no 
 W_TORSION = W_LADDER
 # what the kernel EXECUTES ("The ladder window as one statement"): the re-arranged doubling runs 234 products
 # (M = ZZ^2 + 3 X^2 as one 42-product accumulation), the mixed addition 330, the per-lane table is built in affine
-# coordinates with three shared inversions (3 I + 26 M + 11 S); the comb additions and the final compare are unchanged
+# coordinates with shared inversions; the comb additions and the final compare are unchanged
 W_DBL_EXEC, W_MADD_EXEC = 234, 330
-W_TABLE_EXEC = 3 * W_INV + 26 * F6_MUL + 11 * F6_SQR
-W_VERIFY_EXECUTED = W_TABLE_EXEC + 252 * W_DBL_EXEC + 63 * W_MADD_EXEC + 16 * W_MADD_EXEC + W_FINAL
+# round 4: 16-entry table (1P..16P: four shared inversions, 65 M + 23 S) and signed 5-bit windows: 250 doublings + 51 additions
+W_TABLE_EXEC = 4 * W_INV + 65 * F6_MUL + 23 * F6_SQR
+W_VERIFY_EXECUTED = W_TABLE_EXEC + 250 * W_DBL_EXEC + 51 * W_MADD_EXEC + 16 * W_MADD_EXEC + W_FINAL
 W_HASH = 4 * 7 * (12 * 4 + 12 * 72 + 2 * 144)   # 4 permutations x 7 rounds (80-byte message)
 BYTES_PER_VERIFY = 81 + 96 + 80 + 1             # algorithmic HBM bytes
 # Peak of the multiplier, measured in round 2 (tools/isa_probe, DESIGN.md "instruction cost table"): v_mad_u64_u32
@@ -606,8 +607,9 @@ def main():
                 "algorithmic_bytes_per_launch": BYTES_PER_VERIFY * n,
                 "work_executed": W_VERIFY_EXECUTED,
                 "work_executed_note": "64x64 products the kernel really runs per verification (window statement: 234 per "
-                                      "doubling, 330 per mixed addition; affine table build) -- work_per_unit is the "
-                                      "textbook count kept fixed across rounds, DESIGN.md 'Work formula'",
+                                      "doubling, 330 per mixed addition; 250 doublings + 51 additions over a 16-entry affine "
+                                      "table since round 4) -- work_per_unit is the textbook count of round 1's algorithm, "
+                                      "kept fixed across rounds, DESIGN.md 'Work formula'",
                 "achieved_executed": (W_VERIFY_EXECUTED * n / (k_verify_ms * 1e-3) if k_verify_ms > 0 else 0.0) / 1e9,
                 "pmc": {k: pmc["ssa_k_verify"].get(k) for k in ("SQ_INSTS_VALU", "valu_cycles_per_instruction",
                                                                   "valu_active_frac", "valu_instructions_per_product",

@@ -294,6 +294,37 @@ SSA_DEV u32 sc_nibble(const sc256 &k, u32 w) {
     if (wi == 3) word = k.w[3];
     return (u32)(word >> ((w & 15u) * 4u)) & 15u;
 }
+// The same recoding for signed 5-bit windows (the ladder of the per-lane kernels, round 4: 16-entry tables):
+// k' = k + sum_{w < 50} 16 * 32^w.  digit_w = window5_w(k') - 16 in [-16, 15] for w < 50; what is left above bit 250
+// -- at most 32 for k < 2^255, at most 31 for a scalar below q -- is the unsigned top digit.
+SSA_DEV sc256 sc_recode_offset5(const sc256 &k) {
+    const u64 OFF[4] = {0x0842108421084210ULL, 0x1084210842108421ULL, 0x2108421084210842ULL, 0x0210842108421084ULL};
+    sc256 r;
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 s = k.w[i] + OFF[i];
+        u64 c1 = s < k.w[i];
+        u64 s2 = s + carry;
+        u64 c2 = s2 < s;
+        r.w[i] = s2;
+        carry = c1 | c2;
+    }
+    return r;
+}
+// bits [5 w, 5 w + 5) of a 256-bit value with a dynamic index (w <= 50), registers only
+SSA_DEV u32 sc_win5(const sc256 &k, u32 w) {
+    const u32 bit = 5u * w, wi = bit >> 6, sh = bit & 63u;
+    u64 lo = k.w[0], hi = k.w[1];
+    if (wi == 1) { lo = k.w[1]; hi = k.w[2]; }
+    if (wi == 2) { lo = k.w[2]; hi = k.w[3]; }
+    if (wi == 3) { lo = k.w[3]; hi = 0ull; }
+    u64 v = lo >> sh;
+    if (sh > 59u) v |= hi << (64u - sh);
+    return (u32)v & 31u;
+}
+SSA_DEV u32 sc_top5(const sc256 &k) { return (u32)(k.w[3] >> 58); }   // bits 250..255 of the recoded value
+
 // 16-bit window w (0..15)
 SSA_DEV u32 sc_win16(const sc256 &k, u32 w) {
     const u32 wi = w >> 2;

@@ -10,7 +10,7 @@
 // HBM layout: inputs stay in the caller's AoS byte records (81-B signatures, 96-B keys,
 // message bytes); per-lane intermediates live in the context workspace:
 //   ws_h    n x 4 u64       challenge scalars
-//   ws_tab  n x 8 x 32 u64  per-lane affine multiples 1P..8P (256-B rows: x, y in the first 128-B line; the second
+//   ws_tab  n x 16 x 32 u64 per-lane affine multiples 1P..16P (256-B rows: x, y in the first 128-B line; the second
 //                           line is scratch of the batch normalisation and holds the NEGATIVE entry (x, -y) once the
 //                           table is finished), lane-contiguous so that a lane's gather of one entry -- of either
 //                           sign -- is six 16-byte loads from ONE cache line
@@ -25,7 +25,7 @@ namespace ssa {
 constexpr int GW_BITS = 16;
 constexpr int GW_COUNT = 16;
 constexpr size_t GTAB_ENTRIES = (size_t)GW_COUNT << GW_BITS;
-constexpr int PTAB_ENTRIES = 8;
+constexpr int PTAB_ENTRIES = 16;    // 1P..16P: signed 5-bit windows (round 4; 1P..8P and 4-bit windows before)
 // a table row is 256 B = two 128-B lines: X, Y (affine x, y after the build) in the first -- a gather of the
 // ladder touches exactly one line -- and Z, prefix product of the build in the second
 constexpr int PTAB_ENTRY_U64 = 32, PTAB_Z = 16, PTAB_C = 22;
@@ -273,6 +273,43 @@ SSA_DEV void st_tab_entry(u64 *__restrict__ row, const aff &a) {
     st_f6(row + PTAB_NEG, a.x);
     st_f6(row + PTAB_NY, f6_neg(a.y));
 }
+// 9P .. 16P from the finished rows 1P .. 8P with ONE more shared inversion: mP = 8P + (m - 8)P for odd m, mP = 2 (m/2)P
+// for even m -- eight denominators x8 - x_(m-8) / 2 y_(m/2), their prefix products parked in the rows' second lines
+// (scratch until st_tab_entry writes the negative entry there), Montgomery's trick backwards.  Rolled loops: this runs
+// once per lane and must not cost registers or code.  A zero denominator (keys of small order) returns false before any
+// row of the upper half is final, and the caller builds the table the exact way.
+SSA_DEV bool build_ptab_affine_upper(u64 *__restrict__ tab) {
+    constexpr int R = PTAB_ENTRY_U64;
+    const aff p8 = ld_aff(tab + 7 * R);
+    fp6 c = f6_one();
+#pragma unroll 1
+    for (int m = 9; m <= 16; m++) {
+        const aff b = ld_aff(tab + (((m & 1) ? m - 8 : m / 2) - 1) * R);
+        const fp6 d = (m & 1) ? f6_sub(p8.x, b.x) : f6_dbl(b.y);
+        st_f6(tab + (m - 1) * R + PTAB_Z, d);
+        c = f6_mul(c, d);
+        st_f6(tab + (m - 1) * R + PTAB_C, c);
+    }
+    if (f6_is_zero(c)) return false;
+    fp6 inv = f6_inv(c);
+#pragma unroll 1
+    for (int m = 16; m >= 9; m--) {
+        fp6 di = inv;                                                      // 1 / d_m = inv * prefix_(m-1)
+        if (m > 9) di = f6_mul(inv, ld_f6(tab + (m - 2) * R + PTAB_C));
+        inv = f6_mul(inv, ld_f6(tab + (m - 1) * R + PTAB_Z));
+        const aff b = ld_aff(tab + (((m & 1) ? m - 8 : m / 2) - 1) * R);
+        aff r;
+        if (m & 1) r = aff_from_slope(f6_mul(f6_sub(p8.y, b.y), di), b.x, b.y, p8.x);
+        else r = aff_from_slope(f6_mul(aff_dbl_num(b.x), di), b.x, b.y, b.x);
+        // (row m - 1 is not an operand of any row below it that is still to come: operands are rows 1..8)
+        st_f6(tab + (m - 1) * R, r.x);
+        st_f6(tab + (m - 1) * R + 6, r.y);
+    }
+#pragma unroll 1
+    for (int m = 9; m <= 16; m++) st_tab_entry(tab + (m - 1) * R, ld_aff(tab + (m - 1) * R));   // the negative entries
+    return true;
+}
+
 SSA_DEV bool build_ptab_affine(u64 *__restrict__ tab, const aff &p) {
     constexpr int R = PTAB_ENTRY_U64;
     // 2P
@@ -304,12 +341,12 @@ SSA_DEV bool build_ptab_affine(u64 *__restrict__ tab, const aff &p) {
     st_tab_entry(tab + 5 * R, aff_from_slope(f6_mul(aff_dbl_num(p3.x), i6), p3.x, p3.y, p3.x));
     st_tab_entry(tab + 6 * R, aff_from_slope(f6_mul(f6_sub(p4.y, p3.y), i7), p3.x, p3.y, p4.x));
     st_tab_entry(tab + 7 * R, aff_from_slope(f6_mul(aff_dbl_num(p4.x), i8), p4.x, p4.y, p4.x));
-    return true;
+    return build_ptab_affine_upper(tab);
 }
 
-// Affine multiples 1P..8P of a lane's point into its table rows: 4 doublings + 3 mixed additions
-// in Jacobian form, then one shared inversion (Montgomery's trick) to make every entry affine.
-// Multiples that are the identity (P of order <= 8: E(Fp6) has cofactor 2*5*29*...) are stored as
+// Affine multiples 1P..16P of a lane's point into its table rows the EXACT way (keys the affine builder gives up on):
+// 8 doublings + 7 mixed additions in Jacobian form, then one shared inversion (Montgomery's trick) to make every entry
+// affine.  Multiples that are the identity (P of order <= 16: E(Fp6) has cofactor 2*5*29*...) are stored as
 // the (0, 0) sentinel jac_madd understands.
 SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
     constexpr int R = PTAB_ENTRY_U64;
@@ -332,6 +369,11 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
     tab_dbl(tab + 5 * R, tab + 2 * R);            // 6P
     tab_madd(tab + 6 * R, tab + 5 * R, tab);      // 7P = 6P + P
     tab_dbl(tab + 7 * R, tab + 3 * R);            // 8P
+#pragma unroll 1
+    for (int m = 9; m <= 16; m++) {               // 9P = 8P + P, 10P = 2 (5P), 11P = 10P + P, ...
+        if (m & 1) tab_madd(tab + (m - 1) * R, tab + (m - 2) * R, tab);
+        else tab_dbl(tab + (m - 1) * R, tab + (m / 2 - 1) * R);
+    }
     // forward pass: prefix products of the (non-zero) Z's, kept in the rows' fourth slot
     fp6 c = f6_one();
 #pragma unroll 1
@@ -366,22 +408,23 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
 
 #include "qnaf.inc"
 
-// [k]P, k < 2^255, from the lane's affine table with signed 4-bit windows (offset recoding):
-// the top window only selects its table entry, then 63 x (4 doublings + 1 mixed addition) with
-// every lane in lock-step.
+// [k]P, k < 2^255, from the lane's affine table 1P..16P with signed 5-bit windows (offset recoding): the top digit
+// (<= 32) selects its table entry -- two entries above 16 --, then 50 x (5 doublings + 1 mixed addition) with
+// every lane in lock-step: 250 doublings + 51 additions (round 3, 4-bit windows over 1P..8P: 252 + 63).
 // order_q: [q]P for the subgroup check (is_torsion_free, src/signature.rs:182) -- the scalar is a constant, so its
-// schedule is chosen offline: the width-4 NAF of q (qnaf.inc, tools/gen_qnaf.py), 52 additions and 255 doublings with a
-// variable number of doublings per window instead of 59 + 252 (k is ignored).  Same loop, same window statement: the
+// schedule is chosen offline: the width-5 NAF of q (qnaf.inc, tools/gen_qnaf.py), 43 additions and 255 doublings with a
+// variable number of doublings per window (k is ignored).  Same loop, same window statement: the
 // ladder body exists once in the code.
 SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q = false) {
-    const sc256 kr = sc_recode_offset(k);
+    const sc256 kr = sc_recode_offset5(k);
     jac acc = jac_identity();
-    const u32 top = order_q ? (u32)QNAF_DIGIT[0] : sc_nibble(kr, 63u);   // in [0, 8]
+    const u32 top = order_q ? (u32)QNAF_DIGIT[0] : sc_top5(kr);   // in [0, 32]
     if (top != 0) {
-        const aff p = ld_aff(tab + (top - 1) * PTAB_ENTRY_U64);
+        const aff p = ld_aff(tab + ((top > 16u ? 16u : top) - 1u) * PTAB_ENTRY_U64);
         if (!(f6_is_zero(p.x) && f6_is_zero(p.y))) acc = jac_from_aff(p);
+        if (top > 16u) acc = jac_madd_fast(acc, ld_aff(tab + (top - 17u) * PTAB_ENTRY_U64));   // 16P + (top - 16)P
     }
-    const int steps = order_q ? QNAF_LEN - 1 : 63;
+    const int steps = order_q ? QNAF_LEN - 1 : 50;
 #pragma unroll 1
     for (int it = 0; it < steps; it++) {
         int digit;
@@ -390,8 +433,8 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q =
             digit = (int)QNAF_DIGIT[it + 1];
             gap = (u32)QNAF_GAP[it + 1];
         } else {
-            digit = (int)sc_nibble(kr, (u32)(62 - it)) - 8;
-            gap = 4u;
+            digit = (int)sc_win5(kr, (u32)(49 - it)) - 16;
+            gap = 5u;
         }
         const int mag = digit < 0 ? -digit : digit;
 #ifdef SSA_JAC_ASM

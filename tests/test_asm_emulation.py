@@ -504,7 +504,7 @@ def test_generated_files_are_up_to_date():
 
 def test_order_q_schedule_is_q():
     """qnaf.inc: the (gap, digit) schedule the subgroup check runs evaluates to the subgroup order (plain integers),
-    uses only table rows 1P..7P and never asks the window statement for zero doublings"""
+    uses only the odd table rows 1P..15P and never asks the window statement for zero doublings"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     txt = open(os.path.join(root, "schnorr-sig_amd", "csrc", "qnaf.inc")).read()
     digits = [int(v) for v in re.search(r"QNAF_DIGIT\[QNAF_LEN\] = \{(.*?)\}", txt).group(1).split(",")]
@@ -515,5 +515,6 @@ def test_order_q_schedule_is_q():
     for g, d in zip(gaps, digits):
         acc = (acc << g) + d
     assert acc == 0x7AF2599B3B3F22D0563FBF0F990A37B5327AA72330157722D443623EAED4ACCF
-    assert gaps[0] == 0 and 1 <= digits[0] <= 8 and all(1 <= g <= 64 for g in gaps[1:])
-    assert all(d % 2 and abs(d) <= 7 for d in digits)
+    assert gaps[0] == 0 and 1 <= digits[0] <= 16 and all(1 <= g <= 64 for g in gaps[1:])
+    assert all(d % 2 and abs(d) <= 15 for d in digits)
+    assert n == 44 and sum(gaps) == 255                 # width-5 NAF: 43 additions, 255 doublings
