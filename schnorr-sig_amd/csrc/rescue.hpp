@@ -57,7 +57,11 @@ SSA_DEV u64 inv_sbox(u64 x) {
 // the generator): they REPORT the lanes that met it and hand those lanes their inputs back, and the lanes are
 // recomputed with the compiled, exact chain.  ~1 lane in 3 * 10^5 hashes takes that branch.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SSA_NO_FP_CHAIN_ASM)
+#ifdef SSA_FP_CHAIN_INC          // an alternative generated file (A/B builds: tools/build_variants.sh)
+#include SSA_FP_CHAIN_INC
+#else
 #include "fp_chain_asm.inc"
+#endif
 SSA_DEV void inv_sbox2(u64 &x, u64 &y) {
     if (inv_sbox2_asm(x, y)) {      // flagged lanes get their inputs back (no copy is kept alive across the block)
         x = inv_sbox(x);

@@ -301,12 +301,10 @@ SSA_DEV bool build_ptab_affine_upper(u64 *__restrict__ tab) {
         aff r;
         if (m & 1) r = aff_from_slope(f6_mul(f6_sub(p8.y, b.y), di), b.x, b.y, p8.x);
         else r = aff_from_slope(f6_mul(aff_dbl_num(b.x), di), b.x, b.y, b.x);
-        // (row m - 1 is not an operand of any row below it that is still to come: operands are rows 1..8)
-        st_f6(tab + (m - 1) * R, r.x);
-        st_f6(tab + (m - 1) * R + 6, r.y);
+        // the row's own scratch (its denominator; its prefix product served row m + 1, done before) is dead now: the
+        // finished entry and its negative go straight in (operands of the rows still to come are rows 1..8 only)
+        st_tab_entry(tab + (m - 1) * R, r);
     }
-#pragma unroll 1
-    for (int m = 9; m <= 16; m++) st_tab_entry(tab + (m - 1) * R, ld_aff(tab + (m - 1) * R));   // the negative entries
     return true;
 }
 

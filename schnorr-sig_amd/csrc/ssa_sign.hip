@@ -241,7 +241,7 @@ SSA_FN void ct_response(sc256 *__restrict__ e, const sc256 *__restrict__ r, cons
 // secret scalar bytes -> value mod q
 SSA_FN void ct_load_scalar(sc256 *__restrict__ out, const u8 *__restrict__ p) { *out = sc_reduce256_ct(ld_sc(p)); }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)      // two waves per SIMD: 256 registers (the default allocation took 266 and ran one)
 ssa_k_sign_ct(const DevParams *__restrict__ prm, const u64 *__restrict__ ctab, const u64 *__restrict__ gtab,
               const u8 *__restrict__ sks, const u8 *__restrict__ nonces, MsgView mv, size_t n,
               u8 *__restrict__ pks_out, u8 *__restrict__ sigs_out) {

@@ -160,6 +160,8 @@ class Lane:
                 self.wv(a[0], (self.rv(a[1]) * self.rv(a[2])) & M32)
             elif op == "v_mul_hi_u32":
                 self.wv(a[0], (self.rv(a[1]) * self.rv(a[2])) >> 32)
+            elif op == "v_add_u32":
+                self.wv(a[0], (self.rv(a[1]) + self.rv(a[2])) & M32)
             elif op == "v_or_b32":
                 self.wv(a[0], self.rv(a[1]) | self.rv(a[2]))
             elif op == "v_xor_b32":

@@ -10,13 +10,13 @@ for spec in "$@"; do
     flags=${spec#*:}
     echo "building $name ($flags)"
     (
-        for u in ssa_api ssa_msm; do
+        for u in ssa_api ssa_msm ssa_sign; do
             hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -c -cuid=$u $flags -o build/variants/$name.$u.o \
                 schnorr-sig_amd/csrc/$u.hip &
         done
         wait
         hipcc --offload-arch=gfx950 -fPIC -shared -o build/variants/$name.so build/variants/$name.ssa_api.o \
-            build/variants/$name.ssa_msm.o && rm -f build/variants/$name.ssa_api.o build/variants/$name.ssa_msm.o
+            build/variants/$name.ssa_msm.o build/variants/$name.ssa_sign.o && rm -f build/variants/$name.ssa_*.o
     ) &
 done
 wait

@@ -55,6 +55,7 @@ def regs(c):
 # 8.48 / 8.52 / 8.55 ms with the carry chain -- v_mov_b32 issues at twice the rate of the instructions that write or read
 # an SGPR carry, so the longer head is the faster one.
 MOVES_HEAD = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "carries"
+SQ_MERGE_FAST = os.environ.get("SSA_GEN_SQ_MERGE", "") == "fast"
 DUMMY = "s[24:25]"     # carry-outs nobody reads
 STICKY = 40            # s[40:41] / s[42:43]: lanes of chain 0 / 1 whose reduction met the rare borrow (see the docstring)
 SGPRS = list(range(20, 32)) + list(range(36, 44))
@@ -81,7 +82,15 @@ def square(c):
         ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), DUMMY, X, X + 1, vp(A)), [], []),
         ("v_and_b32 v%d, 1, v%d" % (T + 1, T + 1), [], []),
         ("v_lshrrev_b64 %s, 31, %s" % (vp(H), vp(U)), [], []),
+    ] + ([
         ("v_lshl_or_b32 v%d, v%d, 1, v%d" % (T + 1, U, T + 1), [], []),           # lo = v[T:T+1]
+    ] if not SQ_MERGE_FAST else [
+        # A/B of round 4 (SSA_GEN_SQ_MERGE=fast): the same merge as two instructions of the 32-lanes-per-clock class
+        # (v_add_u32, v_or_b32) instead of one of the 16-lanes-per-clock class -- 12 instructions per squaring instead of
+        # 11, the same 40 cycles on the cost table; measured in profiles/r04/hash_ab.txt
+        ("v_add_u32 v%d, v%d, v%d" % (M, U, U), [], []),                          # (u.lo << 1) mod 2^32
+        ("v_or_b32 v%d, v%d, v%d" % (T + 1, M, T + 1), [], []),
+    ]) + [
         ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, X + 1, vp(H)), [], []),   # hi
         # reduction (see the module docstring): X = EPS * h0 + lo (carry c -> s2), then X + c EPS - h1 as one 64-bit
         # subtraction with borrow-in c; a final borrow while c = 0 is the rare "+ p" case: sticky, repaired by the caller

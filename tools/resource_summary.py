@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Compiler resource summary of every kernel of the library (the code object is authoritative for registers, scratch
-and occupancy -- rocprofv3's VGPR_Count column is not): compiles the two translation units to gfx950
+and occupancy -- rocprofv3's VGPR_Count column is not): compiles the three translation units to gfx950
 assembly and prints NumVgprs / NumAgprs / ScratchSize / Occupancy / code bytes per kernel.
     python3 tools/resource_summary.py > profiles/rNN/resource_summary.txt"""
 import os
@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "schnorr-sig_amd", "csrc")
 def main():
     print("# hipcc -O3 --offload-arch=gfx950 -std=c++17 --cuda-device-only -S; per kernel: code bytes, VGPRs, AGPRs, "
           "scratch bytes/lane, LDS bytes/workgroup, waves/SIMD the registers allow")
-    for unit in ("ssa_api.hip", "ssa_msm.hip"):
+    for unit in ("ssa_api.hip", "ssa_msm.hip", "ssa_sign.hip"):
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "u.s")
             subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-S", "-o", out,
