@@ -572,6 +572,7 @@ def main():
                        "process_group": ("forced one-rank group (RCCL rehearsal)" if rk.forced else "torchrun ranks")
                        if rk.dist is not None else None},
             "ranks": [list(d) for d in devices],
+            "hip_runtime": getattr(ssa, "HIP_RUNTIME_BOUND", None),
             "constants": "builder-default (unpinned)" if unpinned else "caller-supplied blob",
             "parity_unpinned": bool(unpinned),
             "parity_note": "bit-exact against the CPU restatement (oracle/); Rescue constants and generator are not "

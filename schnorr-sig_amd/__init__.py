@@ -69,28 +69,45 @@ class MalformedInput(ValueError):
     """Inputs on which the reference panics (src/signature.rs:186, src/batch.rs:37-44,67)."""
 
 
+HIP_RUNTIME_BOUND = None      # path of the HIP runtime this module loaded ahead of the library, or a note why none was
+
+
 def _share_hip_runtime_with_torch():
     """ONE HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7) and
     ask for it as `libamdhip64.so`; this library asks for `libamdhip64.so.7`.  With torch imported first the loader
     gives us torch's copy (SONAME match); the other way round torch's name does not match /opt/rocm's copy, a second
     runtime is loaded and finds no device ("No HIP GPUs are available").  A process that will use both (device tensors
     handed to the *_device entry points) must share one: when torch is installed and not imported yet, its copy is
-    loaded first.  SSA_NO_TORCH_HIP_PRELOAD=1 turns this off (a process that never imports torch does not need it)."""
+    loaded first.  ONLY libamdhip64.so is loaded -- its RPATH brings torch's own HSA runtime with it; loading the two
+    separately and ignoring a failure could bind the system HIP runtime to torch's HSA (or the reverse), a version mix
+    that only shows as a GPU initialisation failure much later.  What was bound is kept in HIP_RUNTIME_BOUND (bench.py
+    prints it); a failure is a warning, not silence.  SSA_NO_TORCH_HIP_PRELOAD=1 turns this off (a process that never
+    imports torch does not need it)."""
+    global HIP_RUNTIME_BOUND
     import sys
-    if "torch" in sys.modules or os.environ.get("SSA_NO_TORCH_HIP_PRELOAD"):
+    if "torch" in sys.modules:
+        HIP_RUNTIME_BOUND = "torch was imported first: its runtime serves both (SONAME match)"
+        return
+    if os.environ.get("SSA_NO_TORCH_HIP_PRELOAD"):
+        HIP_RUNTIME_BOUND = "system runtime (SSA_NO_TORCH_HIP_PRELOAD)"
+        return
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        HIP_RUNTIME_BOUND = "system runtime (torch is not installed)"
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        HIP_RUNTIME_BOUND = "system runtime (torch carries no libamdhip64.so)"
         return
     try:
-        import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return
-        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
-        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-            path = os.path.join(libdir, name)
-            if os.path.exists(path):
-                C.CDLL(path, mode=C.RTLD_GLOBAL)
-    except OSError:
-        pass            # not loadable here (no ROCm userland around it): the system runtime serves
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        HIP_RUNTIME_BOUND = path
+    except OSError as exc:       # not loadable here (no ROCm userland around it): the system runtime serves
+        import warnings
+        HIP_RUNTIME_BOUND = "system runtime (torch's copy did not load: %s)" % exc
+        warnings.warn("schnorr_sig_amd: torch's HIP runtime %s did not load (%s); importing torch later in this process "
+                      "will bring a second runtime" % (path, exc))
 
 
 def _load():

@@ -378,3 +378,22 @@ def test_keyed_records_and_compression_round_trip(engine, oracle):
     assert ks2 is not None and ks2.verify(b"keyed message", engine) is None
     with pytest.raises(ssa.SignatureError):
         ks2.verify(b"another message", engine)
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """the package first, torch afterwards (the order that once put two HIP runtimes into the process: "No HIP GPUs are
+    available"), and the reverse: both see the device, and the package says which runtime it bound"""
+    for order in ("import schnorr_sig_amd as ssa, torch", "import torch, schnorr_sig_amd as ssa"):
+        code = order + "\n" + (
+            "import numpy as np\n"
+            "assert torch.cuda.is_available() and torch.cuda.device_count() >= 1\n"
+            "eng = ssa.Engine(0)\n"
+            "x = torch.arange(8, device='cuda').sum().item()\n"
+            "s = np.ones((2, 32), np.uint8)\n"
+            "pks, sigs = eng.keygen_sign_many(s, s, np.zeros((2, 8), np.uint8))\n"
+            "print('BOUND', ssa.HIP_RUNTIME_BOUND, x, int(eng.verify_many(sigs, pks, np.zeros((2, 8), np.uint8))[1]))\n")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "BOUND" in r.stdout and " 28 0" in r.stdout, r.stdout
+        bound = r.stdout.split("BOUND", 1)[1]
+        assert ("libamdhip64.so" in bound) or ("torch was imported first" in bound), bound
