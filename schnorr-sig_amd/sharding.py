@@ -126,4 +126,9 @@ def msm_verdict(local_record, world, dist, combine, engine=None):
     records = gather_msm_partials(local_record, world, dist)
     if on_device:
         engine.stream_acquire(torch.cuda.current_stream(local_record.device).cuda_stream)
-    return combine(records), records
+    verdict = combine(records)
+    if on_device:
+        # torch's stream waits for the combination too: `records` (and the verdict buffer) may be released to torch's
+        # caching allocator -- which reuses a block for later work on ITS stream -- while the engine's kernel still reads
+        engine.stream_release(torch.cuda.current_stream(local_record.device).cuda_stream)
+    return verdict, records
