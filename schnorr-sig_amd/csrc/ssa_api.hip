@@ -100,6 +100,10 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         const size_t v = (size_t)std::strtoull(ms, nullptr, 10);
         if (v >= 256 && v <= ((size_t)1 << 23)) ctx->msm_slice = v;
     }
+    if (const char *tg = std::getenv("SSA_MSM_TREE_GROUP")) {
+        const int v = std::atoi(tg);
+        if (v >= 2 && v <= 64) ctx->msm_tree_group = (unsigned)v;
+    }
     if (const char *pc = std::getenv("SSA_PIPELINE_CHUNKS")) {
         const int v = std::atoi(pc);
         if (v >= 1 && v <= 8) ctx->pipeline_chunks = (unsigned)v;

@@ -89,6 +89,7 @@ struct ssa_ctx {
     // combined like the shards of a multi-GPU batch.  SSA_LANE_SLICE / SSA_MSM_SLICE override (tests force small ones).
     size_t lane_slice = (size_t)1 << 20, msm_slice = (size_t)1 << 23;
     DevBuf msm_slice_recs;        // one 24-word record per MSM slice
+    unsigned msm_tree_group = 16; // chunk sums added per cooperating wave and tree level (SSA_MSM_TREE_GROUP: 2..64)
     // signing (ssa_sign.hip): the 4-bit comb table of the constant-time signer (98 KB, built at the first use) and the
     // intermediates of the keyed (130-byte) output
     DevBuf ctab, sg_sigs, sg_pks;

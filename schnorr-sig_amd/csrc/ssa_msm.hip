@@ -38,7 +38,7 @@
 namespace ssa {
 
 constexpr int MSM_CHUNK = 8;   // buckets per lane in the running-sum pass (short chains, many lanes)
-constexpr u32 MSM_TREE_GROUP = 16;  // one cooperating wave sums 16 chunk sums (15 additions of ~2.2 us): 4096 -> 256 -> 16 -> 1
+// (the tree: one cooperating wave sums ctx->msm_tree_group = 16 chunk sums -- 15 additions of ~2.2 us --: 4096 -> 256 -> 16 -> 1)
 
 struct MsmShape {
     u32 c;        // window bits
@@ -1128,9 +1128,9 @@ static int msm_run_one(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks
         u64 *ping = (u64 *)ctx->msm_chunks.p, *pong = (u64 *)ctx->msm_windows.p;
         u32 count = sh.chunks;
         while (count > 1) {
-            const u32 groups = (count + MSM_TREE_GROUP - 1) / MSM_TREE_GROUP;
+            const u32 groups = (count + ctx->msm_tree_group - 1) / ctx->msm_tree_group;
             hipLaunchKernelGGL(msm_k_tree, dim3(sh.windows * groups), dim3(64), 0, ctx->stream,
-                               (const u64 *)ping, sh.windows, count, MSM_TREE_GROUP, pong);
+                               (const u64 *)ping, sh.windows, count, ctx->msm_tree_group, pong);
             u64 *tmp = ping;
             ping = pong;
             pong = tmp;

@@ -29,6 +29,18 @@ while time.time() - t0 < budget:
     sks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); sks[:, 31] &= 0x3F; sks[:, 0] |= 1
     nonces = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); nonces[:, 31] &= 0x3F; nonces[:, 0] |= 1
     pks, sigs = eng.keygen_sign_many(sks, nonces, flat, offsets=off)
+    # round 4: the constant-time signer emits the same bytes (and the oracle's signer on a prefix); keyed records;
+    # PublicKey::to_bytes inverts from_bytes
+    pks_c, recs = eng.keygen_sign_many(sks, nonces, flat, offsets=off, constant_time=True, keyed=True)
+    m_o = min(n, 24)
+    pk_o, sig_o = orc.keygen_sign_many(sks[:m_o], nonces[:m_o], flat, offsets=off[:m_o + 1])
+    comp_k, st_k = eng.compress_many(pks)
+    back_k, inf_k, dst_k = eng.decompress_many(comp_k)
+    if not ((pks_c == pks).all() and (recs[:, 49:] == sigs).all() and (recs[:, :49] == comp_k).all() and
+            (pk_o == pks[:m_o]).all() and (sig_o == sigs[:m_o]).all() and (st_k == 0).all() and (dst_k == 0).all() and
+            (back_k == pks).all() and all(comp_k[i].tobytes() == orc.compress(pks[i].tobytes()) for i in range(m_o))):
+        print("SIGNING / WIRE-FORM MISMATCH iteration", it)
+        sys.exit(1)
     inf = np.zeros(n, dtype=np.uint8)
     kinds = rng.integers(0, 18, size=n)
     for i in np.nonzero(kinds < 10)[0]:
@@ -84,6 +96,16 @@ while time.time() - t0 < budget:
     if v_gpu != v_cpu:
         print("MSM VERDICT MISMATCH iteration", it, v_gpu, v_cpu)
         sys.exit(1)
+    # every fourth iteration: the whole batch through the bucket method (n above the small-batch switch), library-drawn
+    # and caller-supplied coefficients, against the oracle's MSM
+    if it % 4 == 0 and n > 3100:
+        co = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); co[:, 31] &= 0x3F
+        v_cpu = orc.verify_batch_msm(sigs, pks, flat, co, offsets=off, pk_inf=inf)
+        v_gpu = eng.verify_batch_msm(sigs, pks, flat, offsets=off, coeffs=co, pk_inf=inf)
+        v_gpu2 = eng.verify_batch_msm(sigs, pks, flat, offsets=off, pk_inf=inf)
+        if not (v_gpu == v_cpu == v_gpu2):
+            print("BUCKET MSM VERDICT MISMATCH iteration", it, v_gpu, v_gpu2, v_cpu)
+            sys.exit(1)
     # decompression of the generated keys and of random x
     comp = np.zeros((min(n, 256), 49), dtype=np.uint8)
     comp[:, :48] = rng.integers(0, 256, size=(comp.shape[0], 48), dtype=np.uint8)
@@ -100,4 +122,5 @@ while time.time() - t0 < budget:
     if it % 5 == 0:
         print("  ... %d iterations, %d signatures, %.0f s" % (it, total, time.time() - t0), flush=True)
 print("soak ok: %d iterations, %d signatures x 3 semantics x 2 kernel families (+ keyed contexts of both kinds, "
-      "MSM verdicts), %.0f s" % (it, total, time.time() - t0))
+      "MSM verdicts of both paths, constant-time signer = throughput signer = oracle signer, wire forms), %.0f s"
+      % (it, total, time.time() - t0))
