@@ -54,8 +54,9 @@ def regs(c):
 # on one box, alternating (profiles/r03/mul_head_ab.txt): ssa_k_hash 8.36 / 8.39 / 8.40 ms with the moves against
 # 8.48 / 8.52 / 8.55 ms with the carry chain -- v_mov_b32 issues at twice the rate of the instructions that write or read
 # an SGPR carry, so the longer head is the faster one.
-MOVES_HEAD = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "carries"
+MOVES_HEAD = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "carries"       # "moves" (default), "moves10", "carries"
 SQ_MERGE_FAST = os.environ.get("SSA_GEN_SQ_MERGE", "") == "fast"
+MUL_HEAD_ADD1 = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "moves10"     # round 4 default; "moves10" = round 3's head
 DUMMY = "s[24:25]"     # carry-outs nobody reads
 STICKY = 40            # s[40:41] / s[42:43]: lanes of chain 0 / 1 whose reduction met the rare borrow (see the docstring)
 SGPRS = list(range(20, 32)) + list(range(36, 44))
@@ -116,7 +117,7 @@ def multiply(c, saved):
     g = regs(c)
     X, T, A, U, H, C, E, V, S = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved], g["S"]
     S2, S3 = S + 8, S + 16
-    if MOVES_HEAD:
+    if MOVES_HEAD and not MUL_HEAD_ADD1:        # round 3's head: 10 instructions
         return [
             ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),
             ("v_mov_b32 v%d, v%d" % (A, T + 1), [], []),
@@ -129,6 +130,23 @@ def multiply(c, saved):
             ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(A), vp(C)), [], []),       # v[A+1], v[C+1] hold 0
             ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V + 1, vp(E)), [], []),
         ] + reduce_tail(c)
+    if MOVES_HEAD:
+        # round 4: NINE instructions.  The high word of the second cross product joins the top product through a
+        # multiply-add by the inline constant 1 (S0 may be any VGPR, so no zero-extended pair has to be built for it):
+        # x1 s1 + t1.hi + t2.hi <= 2^64 - 1 is the high half of a 128-bit product, it cannot overflow.  One move and the
+        # 64-bit add go; the kernel pays per instruction (profiles/r04/hash_ab.txt).
+        M = g["M"]
+        return [
+            ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),                  # t0 = x0 s0
+            ("v_mov_b32 v%d, v%d" % (A, T + 1), [], []),
+            ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), DUMMY, X, V + 1, vp(A)), [], []),      # t1 = x0 s1 + t0.hi
+            ("v_mov_b32 v%d, v%d" % (A, U), [], []),
+            ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(M), DUMMY, X + 1, V, vp(A)), [], []),      # t2 = x1 s0 + t1.lo
+            ("v_mov_b32 v%d, v%d" % (T + 1, M), [], []),                                           # lo = (t0.lo, t2.lo)
+            ("v_mov_b32 v%d, v%d" % (A, U + 1), [], []),
+            ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V + 1, vp(A)), [], []),  # x1 s1 + t1.hi
+            ("v_mad_u64_u32 %s, %s, v%d, 1, %s" % (vp(H), DUMMY, M + 1, vp(H)), [], []),           # + t2.hi
+        ] + reduce_tail(c)
     head = [
         ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),                   # t0 = x0 s0
         ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(U), DUMMY, X, V + 1), [], []),               # x0 s1
@@ -140,6 +158,15 @@ def multiply(c, saved):
         ("v_addc_co_u32 v%d, %s, 0, v%d, %s" % (H + 1, sp(S2), H + 1, sp(S3)), [], [S2]),       # hi.hi += carry (cannot overflow)
     ]
     return head + reduce_tail(c)
+
+
+def zero_inits(g):
+    """the registers a block expects to hold 0: the high word of the zero-extended addend pair A, and -- for the heads
+    that add two zero-extended words -- of C (low word of C for the carry-chain head)"""
+    out = ["v_mov_b32 v%d, 0" % (g["A"] + 1)]
+    if not (MOVES_HEAD and MUL_HEAD_ADD1):
+        out.append("v_mov_b32 v%d, 0" % (g["C"] + 1 if MOVES_HEAD else g["C"]))
+    return out
 
 
 def copy(c, dst, src):
@@ -175,7 +202,7 @@ def emit_program(name, prog, doc):
     body = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
                           "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
     for g in (g0, g1):
-        body += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1 if MOVES_HEAD else g["C"])]
+        body += zero_inits(g)
     n_loop = 0
     counts = {"valu": 0, "nop": 0}
     sq_body = schedule([square(0), square(1)])
@@ -327,7 +354,7 @@ def generate():
     pre = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
                          "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
     for g in (g0, g1):
-        pre += ["v_mov_b32 v%d, 0" % (g["A"] + 1), "v_mov_b32 v%d, 0" % (g["C"] + 1 if MOVES_HEAD else g["C"])]
+        pre += zero_inits(g)
     pre += ["s_mov_b32 s26, %[n]"]
     for ln in pre:
         lines.append('        "%s\\n\\t"' % ln)
