@@ -448,6 +448,16 @@ extern "C" int ssa_keygen_sign_many_ex(ssa_ctx *ctx, const uint8_t *sks, const u
     if (n == 0) return 0;
     if (!scalars_canonical_nonzero(sks, n) || !scalars_canonical_nonzero(nonces, n)) return SSA_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    // the staged secrets do not outlive the call, whichever way it returns
+    struct Wipe {
+        ssa_ctx *ctx;
+        size_t bytes;
+        ~Wipe() {
+            if (ctx->st_sigs.p && ctx->st_sigs.cap >= bytes) (void)hipMemsetAsync(ctx->st_sigs.p, 0, bytes, ctx->stream);
+            if (ctx->st_pks.p && ctx->st_pks.cap >= bytes) (void)hipMemsetAsync(ctx->st_pks.p, 0, bytes, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+    } wipe{ctx, n * 32};
     StagedInputs s;
     const void *p_sk, *p_nonce;
     if (int rc = stage_up(ctx, ctx->st_sigs, sks, n * 32, &p_sk)) return rc;
@@ -460,9 +470,6 @@ extern "C" int ssa_keygen_sign_many_ex(ssa_ctx *ctx, const uint8_t *sks, const u
         return rc;
     if (pks_out) HIP_TRY(hipMemcpyAsync(pks_out, ctx->st_aux.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(sigs_out, ctx->st_aux2.p, n * sig_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    // the staged secrets do not outlive the call
-    HIP_TRY(hipMemsetAsync(ctx->st_sigs.p, 0, n * 32, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->st_pks.p, 0, n * 32, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
