@@ -419,7 +419,9 @@ msm_k_buckets(const u64 *__restrict__ points, const u32 *__restrict__ vals, cons
 // ---- 4. bucket reduction ------------------------------------------------------------------------
 // chunk of MSM_CHUNK buckets [k0, k0 + L) of a window, bucket k weighing k + 1 (|digit|):
 //   sum_k (k + 1) B_k = sum_k (k - k0 + 1) B_k + k0 sum_k B_k
-__global__ void __launch_bounds__(256, 2)
+// (2^16 lanes are one wave per SIMD anyway: with one wave per SIMD allowed the general addition keeps its values in
+//  registers -- 256 VGPRs + 384 B of scratch before)
+__global__ void __launch_bounds__(256, 1)
 msm_k_chunks(const u64 *__restrict__ bsum, MsmShape sh, u64 *__restrict__ chunk_out) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)sh.windows * sh.chunks) return;
