@@ -243,7 +243,11 @@ int ssa_keygen_sign_many_ex_device(ssa_ctx *ctx, const uint8_t *d_sks, const uin
 int ssa_compress_many_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t n, uint8_t *d_out,
                              uint8_t *d_status_out);
 /* coeff_bytes in 1..32: little-endian coefficient width (d_coeffs == NULL: the library draws 128-bit
- * coefficients as above); *d_verdict_out receives the status */
+ * coefficients as above); *d_verdict_out receives the status.  A 32-byte coefficient is taken mod q (Scalar::random,
+ * src/batch.rs:75-78).  A narrower one is recoded into signed digits over its own windows only, so a value that fills
+ * them to the top (above 0x7fff...7fff with 16-bit windows, n >= 4096; above 0x7f7f...7f with 8-bit ones) stands for
+ * raw - 2^(8 coeff_bytes): the SAME value multiplies R_i, h_i and e_i, so the equation is the reference's with another,
+ * equally random, coefficient (tests/test_gpu_round4.py pins the rule against the oracle). */
 int ssa_verify_batch_msm_device(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks,
                                 const uint8_t *d_pk_inf, const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride,
                                 size_t msg_len, size_t n, const uint8_t *d_coeffs, uint32_t coeff_bytes,

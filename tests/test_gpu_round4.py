@@ -397,3 +397,63 @@ def test_one_hip_runtime_whatever_the_import_order():
         assert "BOUND" in r.stdout and " 28 0" in r.stdout, r.stdout
         bound = r.stdout.split("BOUND", 1)[1]
         assert ("libamdhip64.so" in bound) or ("torch was imported first" in bound), bound
+
+
+@pytest.mark.parametrize("n", [3500, 4200])
+def test_narrow_coefficients_are_the_value_their_signed_digits_represent(engine, oracle, n):
+    """MSM form with 16-byte coefficients (what the library draws and what bench.py passes): the bucket method recodes a
+    coefficient into signed digits over ITS OWN windows -- no carry window -- so a coefficient that carries out of its
+    top window stands for raw - 2^128.  The shard record must be the oracle's sum s_i R_i - s_i h_i P_i / sum s_i e_i with
+    exactly that effective coefficient (mod q) -- n = 3500 runs 8-bit windows, n = 4200 16-bit ones --, and forged
+    batches are rejected whatever the top bits are."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import msm_records as mr
+    rng = np.random.default_rng(4700 + n)
+    sigs, pks, msgs = honest(engine, rng, n, msg_len=24)
+    co = rng.integers(0, 256, size=(n, 16), dtype=np.uint8)
+    co[0] = 0xFF                                   # 2^128 - 1: stands for -1
+    co[1] = 0
+    co[1, 15] = 0x80                               # 2^127: stands for -2^127
+    co[2] = 0x7F                                   # 0x7f7f...7f: the largest value 8-bit windows take as it is
+    co[3] = np.frombuffer(bytes.fromhex("ff7f" * 8), np.uint8)   # 0x7fff...7fff (little-endian): the same for 16-bit windows
+    c = 16 if n >= 4096 else 8
+    top = int.from_bytes(bytes([0xFF] * (c // 8 - 1) + [0x7F]) * (128 // c), "little")   # largest positive value of the digits
+    eff = []
+    for i in range(n):
+        s = int.from_bytes(co[i].tobytes(), "little")
+        eff.append(((s if s <= top else s - (1 << 128)) % Q).to_bytes(32, "little"))
+    eff = np.frombuffer(b"".join(eff), np.uint8).reshape(n, 32)
+    dev = torch.device("cuda", 0)
+    ds, dp, dm, dc = (torch.from_numpy(a).to(dev) for a in (sigs, pks, msgs, co))
+    rec = torch.zeros(24, dtype=torch.int64, device=dev)
+    engine.verify_batch_msm_partial_device(ds.data_ptr(), dp.data_ptr(), dm.data_ptr(), n, 24, dc.data_ptr(), 16,
+                                           rec.data_ptr())
+    engine.sync()
+    rec = rec.cpu().numpy().astype(np.uint64)
+    m = 600                                        # the oracle's record of a prefix is enough to pin the rule ...
+    rec_m = torch.zeros(24, dtype=torch.int64, device=dev)
+    # ... but the prefix must take the same path as the whole: run it inside a batch of the same size by zeroing the
+    # other coefficients (a zero coefficient contributes nothing to either side)
+    co_m = co.copy()
+    co_m[m:] = 0
+    dcm = torch.from_numpy(co_m).to(dev)
+    engine.verify_batch_msm_partial_device(ds.data_ptr(), dp.data_ptr(), dm.data_ptr(), n, 24, dcm.data_ptr(), 16,
+                                           rec_m.data_ptr())
+    engine.sync()
+    rec_m = rec_m.cpu().numpy().astype(np.uint64)
+    pt, lin, mal = mr.cpu_partial(oracle, sigs[:m], pks[:m], msgs[:m], eff[:m])
+    assert not mal and int(rec_m[22]) == 0
+    assert mr.record_point(oracle, rec_m) == pt and mr.record_lin(rec_m) == lin
+    # the whole batch: the left-hand point equals [lin] G (honest batch), i.e. the combination says Ok; one forged
+    # signature -- in a lane whose coefficient carries out, and in one whose does not -- says InvalidSignature
+    assert engine.msm_combine(rec.reshape(1, 24)) == 0
+    verdict = torch.full((1,), 255, dtype=torch.int32, device=dev)
+    for lane in (0, 2, n - 1):
+        bad = sigs.copy()
+        bad[lane, 50] ^= 1
+        db = torch.from_numpy(bad).to(dev)
+        engine.verify_batch_msm_device(db.data_ptr(), dp.data_ptr(), dm.data_ptr(), n, 24, dc.data_ptr(), 16,
+                                       verdict.data_ptr())
+        engine.sync()
+        assert int(verdict.item()) == 2, lane
