@@ -325,14 +325,17 @@ SSA_DEV u32 sc_win5(const sc256 &k, u32 w) {
 }
 SSA_DEV u32 sc_top5(const sc256 &k) { return (u32)(k.w[3] >> 58); }   // bits 250..255 of the recoded value
 
-// 16-bit window w (0..15)
-SSA_DEV u32 sc_win16(const sc256 &k, u32 w) {
-    const u32 wi = w >> 2;
-    u64 word = k.w[0];
-    if (wi == 1) word = k.w[1];
-    if (wi == 2) word = k.w[2];
-    if (wi == 3) word = k.w[3];
-    return (u32)(word >> ((w & 3u) * 16u)) & 0xffffu;
+// bits [bit, bit + n) of a 256-bit value (n <= 32) with a dynamic position, registers only; bits above 255 read 0
+SSA_DEV u32 sc_bits(const sc256 &k, u32 bit, u32 n) {
+    const u32 wi = bit >> 6, sh = bit & 63u;
+    u64 lo = k.w[0], hi = k.w[1];
+    if (wi == 1) { lo = k.w[1]; hi = k.w[2]; }
+    if (wi == 2) { lo = k.w[2]; hi = k.w[3]; }
+    if (wi == 3) { lo = k.w[3]; hi = 0ull; }
+    if (wi > 3) { lo = 0ull; hi = 0ull; }
+    u64 v = lo >> sh;
+    if (sh + n > 64u) v |= hi << (64u - sh);
+    return (u32)(v & ((1ull << n) - 1ull));
 }
 
 // Curve equation check y^2 == x^3 + x + (u + 395)

@@ -135,13 +135,19 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
-    if (hipMemcpy(ctx->d_params, &hp, sizeof hp, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemsetAsync(ctx->d_gtab, 0, GTAB_ENTRIES * 12 * sizeof(u64), ctx->stream) != hipSuccess) {
+    if (hipMemcpy(ctx->d_params, &hp, sizeof hp, hipMemcpyHostToDevice) != hipSuccess) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
-    hipLaunchKernelGGL(ssa_k_gtable, dim3(grid_for(GTAB_ENTRIES, 256)), dim3(256), 0, ctx->stream,
-                       ctx->d_params, ctx->d_gtab);
+    // the comb table: 49 152 base entries by double-and-add, then one affine addition per entry (ssa_kernels.hpp)
+    if (ctx->gbase.reserve(GBASE_ENTRIES * 12 * sizeof(u64))) {
+        ssa_ctx_destroy(ctx);
+        return SSA_ERR_HIP;
+    }
+    hipLaunchKernelGGL(ssa_k_gbase, dim3(grid_for(GBASE_ENTRIES, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                       (u64 *)ctx->gbase.p);
+    hipLaunchKernelGGL(ssa_k_gtable, dim3(grid_for(GTAB_ENTRIES / 8, 256)), dim3(256), 0, ctx->stream,
+                       (const u64 *)ctx->gbase.p, ctx->d_gtab);
     if (hipGetLastError() != hipSuccess || ctx->ws_fail.reserve(64)) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
@@ -186,7 +192,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
                       &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
                       &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
-                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks})
+                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks, &ctx->gbase})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);

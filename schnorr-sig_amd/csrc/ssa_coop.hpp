@@ -681,10 +681,10 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
             for (int k = 0; k < 4; k++) h.w[k] = sh.h[k];
             coop_mul_table(L, h, lane, ws);                               // [h]P
 #pragma unroll 1
-            for (int w = 0; w < 16; w++) {                                // + [e]G, src/signature.rs:196-198
-                const u32 d = sc_win16(e, (u32)w);
+            for (int w = 0; w < GW_COUNT; w++) {                          // + [e]G, src/signature.rs:196-198
+                const u32 d = sc_gwin(e, (u32)w);
                 if (d != 0) {
-                    const u64 *rowp = gtab + (((size_t)w << 16) + d) * 12;
+                    const u64 *rowp = gtab + (((size_t)w << GW_BITS) + d) * 12;
                     if (lane < 24) {   // lanes 0..11: x, 7x; lanes 12..23: y, 7y
                         const u32 half = lane / 12u, c = lane % 12u;
                         const u64 v = rowp[6u * half + c % 6u];

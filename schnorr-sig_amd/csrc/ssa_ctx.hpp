@@ -93,6 +93,7 @@ struct ssa_ctx {
     // signing (ssa_sign.hip): the 4-bit comb table of the constant-time signer (98 KB, built at the first use) and the
     // intermediates of the keyed (130-byte) output
     DevBuf ctab, sg_sigs, sg_pks;
+    DevBuf gbase;                 // the two 2048-entry base tables per window the comb table is assembled from (4.7 MB)
     bool ctab_ready = false;
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;

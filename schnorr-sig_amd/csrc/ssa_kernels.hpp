@@ -14,7 +14,7 @@
 //                           line is scratch of the batch normalisation and holds the NEGATIVE entry (x, -y) once the
 //                           table is finished), lane-contiguous so that a lane's gather of one entry -- of either
 //                           sign -- is six 16-byte loads from ONE cache line
-//   gtab    16 x 65536 x 12 u64 affine multiples d*2^(16w)*G (100 MB, Infinity-Cache resident)
+//   gtab    12 x 2^22 x 12 u64 affine multiples d*2^(22w)*G (4.8 GB)
 #pragma once
 #include "curve.hpp"
 #include "fp3.hpp"
@@ -22,9 +22,16 @@
 
 namespace ssa {
 
-constexpr int GW_BITS = 16;
-constexpr int GW_COUNT = 16;
+// Fixed-base comb for G: gtab[w][d] = affine [d 2^(22 w)] G, 12 windows of 22 bits -- [e]G is 12 mixed additions and no
+// doubling (round 4; 16 windows of 16 bits and 16 additions before).  4.8 GB: sized for the 288 GB of the part, not
+// for a cache -- a lane gathers 12 rows in 13 ms of ladder, the second wave of the SIMD covers the misses.
+constexpr int GW_BITS = 22;
+constexpr int GW_COUNT = 12;
 constexpr size_t GTAB_ENTRIES = (size_t)GW_COUNT << GW_BITS;
+// the table is assembled from two small ones per window: gbase[w][h][d] = [d 2^(22 w + 11 h)] G, d < 2048
+constexpr int GB_BITS = GW_BITS / 2;
+constexpr size_t GBASE_ENTRIES = (size_t)GW_COUNT * 2 << GB_BITS;
+SSA_DEV u32 sc_gwin(const sc256 &k, u32 w) { return sc_bits(k, w * (u32)GW_BITS, (u32)GW_BITS); }
 constexpr int PTAB_ENTRIES = 16;    // 1P..16P: signed 5-bit windows (round 4; 1P..8P and 4-bit windows before)
 // a table row is 256 B = two 128-B lines: X, Y (affine x, y after the build) in the first -- a gather of the
 // ladder touches exactly one line -- and Z, prefix product of the build in the second
@@ -457,11 +464,11 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q =
     return acc;
 }
 
-// acc += [e]G from the comb table: one mixed addition per non-zero 16-bit window
+// acc += [e]G from the comb table: one mixed addition per non-zero 22-bit window
 SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e) {
 #pragma unroll 1
     for (int w = 0; w < GW_COUNT; w++) {
-        const u32 d = sc_win16(e, (u32)w);
+        const u32 d = sc_gwin(e, (u32)w);
         if (d != 0) {
             const aff q = ld_aff(gtab + (((size_t)w << GW_BITS) + d) * 12);
             acc = jac_madd_fast(acc, q);
@@ -752,13 +759,19 @@ ssa_k_verify_keyed_comb(const u8 *__restrict__ sigs, const u32 *__restrict__ key
 #endif  // SSA_NO_KERNELS
 
 // ------------------------------------------------------------------------------------------
-// gtab[w][d] = affine [d * 2^(16 w)] G, d = 1..65535 (d = 0 rows stay zero and are never read)
+// The comb table in two steps (round 4; one double-and-add chain of ~250 doublings PER ENTRY before: 13.5 ms for 2^20
+// entries, which would be 0.7 s for the 5 * 10^7 of the 22-bit table):
+//   ssa_k_gbase   gbase[w][h][d] = affine [d 2^(22 w + 11 h)] G for d < 2048: 49 152 entries the slow way (0.7 ms)
+//   ssa_k_gtable  gtab[w][d] = gbase[w][1][d >> 11] + gbase[w][0][d & 2047]: ONE affine addition per entry, a lane
+//                 takes 8 consecutive entries (same high part) and inverts their 8 denominators together; no exceptional
+//                 case can occur between the two parts (d_hi 2^11 = +-d_lo (mod q) has no solution below 2^22), only zero
+//                 parts, which copy the other one.  d = 0 rows are (0, 0) and are never read.
 #ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
-ssa_k_gtable(const DevParams *__restrict__ prm, u64 *__restrict__ gtab) {
+ssa_k_gbase(const DevParams *__restrict__ prm, u64 *__restrict__ gbase) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= GTAB_ENTRIES) return;
-    const u32 w = (u32)(t >> GW_BITS), d = (u32)(t & ((1u << GW_BITS) - 1u));
+    if (t >= GBASE_ENTRIES) return;
+    const u32 d = (u32)(t & ((1u << GB_BITS) - 1u)), wh = (u32)(t >> GB_BITS);   // wh = 2 w + h
     aff g;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -767,18 +780,52 @@ ssa_k_gtable(const DevParams *__restrict__ prm, u64 *__restrict__ gtab) {
     }
     jac acc = jac_identity();
 #pragma unroll 1
-    for (int b = GW_BITS - 1; b >= 0; b--) {
+    for (int b = GB_BITS - 1; b >= 0; b--) {
         acc = jac_dbl(acc);
         if ((d >> b) & 1u) acc = jac_madd(acc, g);
     }
 #pragma unroll 1
-    for (u32 s = 0; s < w * GW_BITS; s++) acc = jac_dbl(acc);
-    const aff a = jac_to_aff(acc);
-    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(gtab + t * 12);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        q[i] = make_ulonglong2(a.x.c[2 * i], a.x.c[2 * i + 1]);
-        q[3 + i] = make_ulonglong2(a.y.c[2 * i], a.y.c[2 * i + 1]);
+    for (u32 s = 0; s < wh * GB_BITS; s++) acc = jac_dbl(acc);
+    st_aff(gbase + t * 12, jac_to_aff(acc));          // the identity (d = 0) as (0, 0)
+}
+
+__global__ void __launch_bounds__(256)
+ssa_k_gtable(const u64 *__restrict__ gbase, u64 *__restrict__ gtab) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= GTAB_ENTRIES / 8) return;
+    const u32 w = (u32)((t * 8) >> GW_BITS), d0 = (u32)((t * 8) & ((1u << GW_BITS) - 1u));
+    const u32 dhi = d0 >> GB_BITS, dlo0 = d0 & ((1u << GB_BITS) - 1u);
+    const u64 *slo = gbase + ((size_t)(2 * w) << GB_BITS) * 12, *shi = gbase + ((size_t)(2 * w + 1) << GB_BITS) * 12;
+    u64 *out = gtab + (((size_t)w << GW_BITS) + d0) * 12;
+    if (dhi == 0) {                                   // only the low part: copies (row 0 of gbase is (0, 0))
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) st_aff(out + 12 * k, ld_aff(slo + (size_t)(dlo0 + k) * 12));
+        return;
+    }
+    const aff p1 = ld_aff(shi + (size_t)dhi * 12);
+    const int first = dlo0 == 0 ? 1 : 0;              // d_lo = 0 (only ever the first of the eight): the high part itself
+    if (first) st_aff(out, p1);
+    // forward: prefix products of the denominators x2 - x1, parked in the output rows
+    fp6 c = f6_one();
+#pragma unroll 1
+    for (int k = first; k < 8; k++) {
+        const fp6 x2 = ld_f6(slo + (size_t)(dlo0 + k) * 12);
+        c = f6_mul(c, f6_sub(x2, p1.x));
+        st_f6(out + 12 * k, c);
+    }
+    fp6 inv = f6_inv(c);
+#pragma unroll 1
+    for (int k = 7; k >= first; k--) {
+        const aff p2 = ld_aff(slo + (size_t)(dlo0 + k) * 12);
+        const fp6 a = f6_sub(p2.x, p1.x);
+        fp6 ai = inv;                                  // 1 / a_k = inv * prefix_(k-1)
+        if (k > first) ai = f6_mul(inv, ld_f6(out + 12 * (k - 1)));
+        inv = f6_mul(inv, a);
+        const aff r = aff_from_slope(f6_mul(f6_sub(p2.y, p1.y), ai), p1.x, p1.y, p2.x);
+        aff rc;
+        rc.x = f6_canon(r.x);
+        rc.y = f6_canon(r.y);
+        st_aff(out + 12 * k, rc);
     }
 }
 #endif  // SSA_NO_KERNELS

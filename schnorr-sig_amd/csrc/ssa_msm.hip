@@ -613,7 +613,7 @@ msm_k_finish(const u64 *__restrict__ win_in, MsmShape sh, const u64 *__restrict_
         coop_set(L, 23, 0ull, lane, ws);
 #pragma unroll 1
         for (int w = 0; w < (partial_out ? 0 : GW_COUNT); w++) {      // BASEPOINT_TABLE.multiply_vartime
-            const u32 d = sc_win16(lin, (u32)w);
+            const u32 d = sc_gwin(lin, (u32)w);
             if (d != 0) {
                 const u64 *rowp = gtab + (((size_t)w << GW_BITS) + d) * 12;
                 if (lane < 24) {
