@@ -4,6 +4,7 @@
 #define SSA_KERNELS_DEFINE 1
 #include "ssa_ctx.hpp"
 
+#include <mutex>
 #include <thread>
 
 static const unsigned char k_default_params[SSA_PARAMS_LENGTH] = {
@@ -41,6 +42,70 @@ struct ssa_keyset {
         ktab.release();
     }
 };
+
+// The comb table depends on the device and the generator only, and it is 4.8 GB: contexts of one process share it
+// (reference-counted; ssa_multi_create with several contexts per device, the tests' many engines, a binding that makes
+// a context per thread).  Built at the first acquisition on the acquiring context's stream, synchronously, under the
+// registry's lock; read-only afterwards.
+struct SharedGtab {
+    int device = 0;
+    u64 gen[12] = {};
+    u64 *d_gtab = nullptr;
+    int refs = 0;
+};
+static std::mutex g_gtab_mu;
+static std::vector<SharedGtab *> g_gtabs;
+
+static SharedGtab *gtab_acquire(ssa_ctx *ctx, const DevParams &hp) {
+    std::lock_guard<std::mutex> lock(g_gtab_mu);
+    u64 gen[12];
+    for (int i = 0; i < 6; i++) {
+        gen[i] = hp.gen_x[i];
+        gen[6 + i] = hp.gen_y[i];
+    }
+    for (SharedGtab *g : g_gtabs)
+        if (g->device == ctx->device && std::memcmp(g->gen, gen, sizeof gen) == 0) {
+            g->refs++;
+            return g;
+        }
+    SharedGtab *g = new SharedGtab();
+    g->device = ctx->device;
+    std::memcpy(g->gen, gen, sizeof gen);
+    // 49 152 base entries by double-and-add, then one affine addition per entry (ssa_kernels.hpp)
+    void *gbase = nullptr;
+    bool ok = hipMalloc((void **)&g->d_gtab, GTAB_ENTRIES * 12 * sizeof(u64)) == hipSuccess &&
+              hipMalloc(&gbase, GBASE_ENTRIES * 12 * sizeof(u64)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(ssa_k_gbase, dim3(grid_for(GBASE_ENTRIES, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                           (u64 *)gbase);
+        hipLaunchKernelGGL(ssa_k_gtable, dim3(grid_for(GTAB_ENTRIES / 8, 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)gbase, g->d_gtab);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (gbase) (void)hipFree(gbase);
+    if (!ok) {
+        if (g->d_gtab) (void)hipFree(g->d_gtab);
+        delete g;
+        return nullptr;
+    }
+    g->refs = 1;
+    g_gtabs.push_back(g);
+    return g;
+}
+
+static void gtab_release(SharedGtab *g) {
+    if (!g) return;
+    std::lock_guard<std::mutex> lock(g_gtab_mu);
+    if (--g->refs > 0) return;
+    for (size_t i = 0; i < g_gtabs.size(); i++)
+        if (g_gtabs[i] == g) {
+            g_gtabs.erase(g_gtabs.begin() + (long)i);
+            break;
+        }
+    (void)hipSetDevice(g->device);
+    (void)hipFree(g->d_gtab);
+    delete g;
+}
 
 static int validate_params(const DevParams &p) {
     if (std::memcmp(p.magic, "SSAPARM1", 8) != 0) return SSA_ERR_PARAMS;
@@ -130,8 +195,7 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
             return SSA_ERR_HIP;
         }
     ctx->stream = ctx->own_stream;
-    if (hipMalloc((void **)&ctx->d_params, sizeof(DevParams)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_gtab, GTAB_ENTRIES * 12 * sizeof(u64)) != hipSuccess) {
+    if (hipMalloc((void **)&ctx->d_params, sizeof(DevParams)) != hipSuccess) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
@@ -139,19 +203,13 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
-    // the comb table: 49 152 base entries by double-and-add, then one affine addition per entry (ssa_kernels.hpp)
-    if (ctx->gbase.reserve(GBASE_ENTRIES * 12 * sizeof(u64))) {
+    // the comb table of this generator on this device: shared by every context that asks for it (4.8 GB)
+    ctx->gtab_share = gtab_acquire(ctx, hp);
+    if (!ctx->gtab_share || ctx->ws_fail.reserve(64)) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
-    hipLaunchKernelGGL(ssa_k_gbase, dim3(grid_for(GBASE_ENTRIES, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
-                       (u64 *)ctx->gbase.p);
-    hipLaunchKernelGGL(ssa_k_gtable, dim3(grid_for(GTAB_ENTRIES / 8, 256)), dim3(256), 0, ctx->stream,
-                       (const u64 *)ctx->gbase.p, ctx->d_gtab);
-    if (hipGetLastError() != hipSuccess || ctx->ws_fail.reserve(64)) {
-        ssa_ctx_destroy(ctx);
-        return SSA_ERR_HIP;
-    }
+    ctx->d_gtab = ctx->gtab_share->d_gtab;
     // the generator must be a point of the prime-order subgroup: on the curve, [q]G == O (through the comb table
     // just built), G != O -- otherwise every verification would run on some other curve or a small subgroup
     unsigned gen_ok = 0;
@@ -192,10 +250,12 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
                       &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
                       &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
-                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks, &ctx->gbase})
+                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
-    if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+    gtab_release(ctx->gtab_share);
+    ctx->gtab_share = nullptr;
+    ctx->d_gtab = nullptr;
     for (auto &ev : ctx->copy_done)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->hash_done)

@@ -68,7 +68,8 @@ struct ssa_ctx {
     size_t pipeline_min_n = 1 << 17;          // host-buffer batches from this size on are uploaded in chunks
     unsigned pipeline_chunks = 8;             // SSA_PIPELINE_CHUNKS overrides (1 = off)
     DevParams *d_params = nullptr;
-    u64 *d_gtab = nullptr;
+    u64 *d_gtab = nullptr;                    // the comb table for G: owned by gtab_share (one per device and generator)
+    struct SharedGtab *gtab_share = nullptr;
     DevBuf ws_h, ws_tab, ws_fail;
     // staging for the host-buffer entry points
     DevBuf st_sigs, st_pks, st_inf, st_msgs, st_off, st_status, st_aux, st_aux2;
@@ -93,7 +94,6 @@ struct ssa_ctx {
     // signing (ssa_sign.hip): the 4-bit comb table of the constant-time signer (98 KB, built at the first use) and the
     // intermediates of the keyed (130-byte) output
     DevBuf ctab, sg_sigs, sg_pks;
-    DevBuf gbase;                 // the two 2048-entry base tables per window the comb table is assembled from (4.7 MB)
     bool ctab_ready = false;
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
     std::map<std::string, std::vector<TimedLaunch>> timed;
