@@ -50,7 +50,7 @@ W_ADD = 11 * F6_MUL + 5 * F6_SQR                # general Jacobian addition
 W_LADDER = 252 * W_DBL + 63 * W_MADD            # 64 signed 4-bit windows (top one is a table pick)
 W_INV = 4 * F6_MUL + 6 + 72 + 6                 # Fp6 inverse through the norm + one Fp inverse
 W_TABLE = 4 * W_DBL + 3 * W_MADD + 18 * F6_MUL + W_INV + 7 * (3 * F6_MUL + F6_SQR)  # 2P..8P, normalised
-W_BASE = 16 * W_MADD                            # comb, 16-bit windows (round 4 runs 12 additions over 22-bit windows)
+W_BASE = 16 * W_MADD                            # comb, 16-bit windows (round 4 runs 11 additions over 24-bit windows)
 W_FINAL = F6_MUL + F6_SQR + 2 * F6_SQR + F6_MUL  # x*Z^2 compare + on-curve check
 W_VERIFY_KERNEL = W_TABLE + W_LADDER + W_BASE + W_FINAL
 W_VERIFY_KEYED = W_LADDER + W_BASE + F6_MUL + F6_SQR   # keyed context: table and key checks are cached
@@ -62,7 +62,7 @@ W_TORSION = W_LADDER
 W_DBL_EXEC, W_MADD_EXEC = 234, 330
 # round 4: 16-entry table (1P..16P: four shared inversions, 65 M + 23 S) and signed 5-bit windows: 250 doublings + 51 additions
 W_TABLE_EXEC = 4 * W_INV + 65 * F6_MUL + 23 * F6_SQR
-W_VERIFY_EXECUTED = W_TABLE_EXEC + 250 * W_DBL_EXEC + 51 * W_MADD_EXEC + 12 * W_MADD_EXEC + W_FINAL   # 22-bit comb: 12 additions
+W_VERIFY_EXECUTED = W_TABLE_EXEC + 250 * W_DBL_EXEC + 51 * W_MADD_EXEC + 11 * W_MADD_EXEC + W_FINAL   # 24-bit comb: 11 additions
 W_HASH = 4 * 7 * (12 * 4 + 12 * 72 + 2 * 144)   # 4 permutations x 7 rounds (80-byte message)
 BYTES_PER_VERIFY = 81 + 96 + 80 + 1             # algorithmic HBM bytes
 # Peak of the multiplier, measured in round 2 (tools/isa_probe, DESIGN.md "instruction cost table"): v_mad_u64_u32

@@ -93,7 +93,7 @@ typedef struct ssa_ctx ssa_ctx;
  * upstream's (they live in un-vendored crates; DESIGN.md "parity unpinned"): such a context rejects every genuine
  * toposware signature and ssa_ctx_uses_default_params() returns 1 for it.  tools/blob_from_upstream.py builds the
  * blob from upstream's constants.  The generator is validated on the device (on the curve, [q]G == O):
- * SSA_ERR_PARAMS otherwise.  Device memory: the fixed-base comb table of the generator is 4.8 GB -- one per device and
+ * SSA_ERR_PARAMS otherwise.  Device memory: the fixed-base comb table of the generator is 17.7 GB -- one per device and
  * generator, shared by all the contexts of the process --, the per-lane workspaces grow to 4.4 GB with the first large
  * batch (slices of 2^20 lanes, whatever the batch size). */
 int ssa_ctx_create(ssa_ctx **out, int device, const void *params, size_t params_len);

@@ -14,7 +14,7 @@
 //                           line is scratch of the batch normalisation and holds the NEGATIVE entry (x, -y) once the
 //                           table is finished), lane-contiguous so that a lane's gather of one entry -- of either
 //                           sign -- is six 16-byte loads from ONE cache line
-//   gtab    12 x 2^22 x 12 u64 affine multiples d*2^(22w)*G (4.8 GB)
+//   gtab    11 x 2^24 x 12 u64 affine multiples d*2^(24w)*G (17.7 GB, shared by the contexts of a process)
 #pragma once
 #include "curve.hpp"
 #include "fp3.hpp"
@@ -22,13 +22,14 @@
 
 namespace ssa {
 
-// Fixed-base comb for G: gtab[w][d] = affine [d 2^(22 w)] G, 12 windows of 22 bits -- [e]G is 12 mixed additions and no
-// doubling (round 4; 16 windows of 16 bits and 16 additions before).  4.8 GB: sized for the 288 GB of the part, not
-// for a cache -- a lane gathers 12 rows in 13 ms of ladder, the second wave of the SIMD covers the misses.
-constexpr int GW_BITS = 22;
-constexpr int GW_COUNT = 12;
+// Fixed-base comb for G: gtab[w][d] = affine [d 2^(24 w)] G, 11 windows of 24 bits -- [e]G is 11 mixed additions and no
+// doubling (round 4; 16 windows of 16 bits and 16 additions before).  17.7 GB, ONE per device and generator shared by the
+// contexts of a process: sized for the 288 GB of the part, not for a cache -- a lane gathers 11 rows in 13 ms of ladder,
+// the second wave of the SIMD covers the misses.  (Measured: 16 bits 27.08 ms, 22 bits 26.70, 24 bits 26.57 for ssa_k_verify.)
+constexpr int GW_BITS = 24;
+constexpr int GW_COUNT = 11;
 constexpr size_t GTAB_ENTRIES = (size_t)GW_COUNT << GW_BITS;
-// the table is assembled from two small ones per window: gbase[w][h][d] = [d 2^(22 w + 11 h)] G, d < 2048
+// the table is assembled from two small ones per window: gbase[w][h][d] = [d 2^(24 w + 12 h)] G, d < 4096
 constexpr int GB_BITS = GW_BITS / 2;
 constexpr size_t GBASE_ENTRIES = (size_t)GW_COUNT * 2 << GB_BITS;
 SSA_DEV u32 sc_gwin(const sc256 &k, u32 w) { return sc_bits(k, w * (u32)GW_BITS, (u32)GW_BITS); }
@@ -464,7 +465,7 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q =
     return acc;
 }
 
-// acc += [e]G from the comb table: one mixed addition per non-zero 22-bit window
+// acc += [e]G from the comb table: one mixed addition per non-zero 24-bit window
 SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e) {
 #pragma unroll 1
     for (int w = 0; w < GW_COUNT; w++) {
@@ -760,11 +761,12 @@ ssa_k_verify_keyed_comb(const u8 *__restrict__ sigs, const u32 *__restrict__ key
 
 // ------------------------------------------------------------------------------------------
 // The comb table in two steps (round 4; one double-and-add chain of ~250 doublings PER ENTRY before: 13.5 ms for 2^20
-// entries, which would be 0.7 s for the 5 * 10^7 of the 22-bit table):
-//   ssa_k_gbase   gbase[w][h][d] = affine [d 2^(22 w + 11 h)] G for d < 2048: 49 152 entries the slow way (0.7 ms)
-//   ssa_k_gtable  gtab[w][d] = gbase[w][1][d >> 11] + gbase[w][0][d & 2047]: ONE affine addition per entry, a lane
-//                 takes 8 consecutive entries (same high part) and inverts their 8 denominators together; no exceptional
-//                 case can occur between the two parts (d_hi 2^11 = +-d_lo (mod q) has no solution below 2^22), only zero
+// entries, which would be 2.5 s for the 1.8 * 10^8 of the 24-bit table):
+//   ssa_k_gbase   gbase[w][h][d] = affine [d 2^(24 w + 12 h)] G for d < 4096: 90 112 entries the slow way (1.3 ms)
+//   ssa_k_gtable  gtab[w][d] = gbase[w][1][d >> 12] + gbase[w][0][d & 4095]: ONE affine addition per entry, a lane
+//                 takes 8 consecutive entries (same high part) and inverts their 8 denominators together (23 ms in all);
+//                 no exceptional case can occur between the two parts (d_hi 2^12 = +-d_lo (mod q) has no solution below
+//                 2^24), only zero
 //                 parts, which copy the other one.  d = 0 rows are (0, 0) and are never read.
 #ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
