@@ -54,7 +54,8 @@ W_BASE = 16 * W_MADD                            # comb, 16-bit windows (round 4 
 W_FINAL = F6_MUL + F6_SQR + 2 * F6_SQR + F6_MUL  # x*Z^2 compare + on-curve check
 W_VERIFY_KERNEL = W_TABLE + W_LADDER + W_BASE + W_FINAL
 W_VERIFY_KEYED = W_LADDER + W_BASE + F6_MUL + F6_SQR   # keyed context: table and key checks are cached
-W_VERIFY_KEYED_COMB = (32 + 16) * W_MADD + F6_MUL + F6_SQR   # per-key comb: no doublings at all
+W_VERIFY_KEYED_COMB = (32 + 16) * W_MADD + F6_MUL + F6_SQR   # per-key comb: no doublings at all (textbook count of round 2:
+                                                             # 8-bit key windows + 16-bit comb; round 4 executes 16 + 11 additions)
 W_TORSION = W_LADDER
 # what the kernel EXECUTES ("The ladder window as one statement"): the re-arranged doubling runs 234 products
 # (M = ZZ^2 + 3 X^2 as one 42-product accumulation), the mixed addition 330, the per-lane table is built in affine

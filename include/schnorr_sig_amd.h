@@ -265,9 +265,9 @@ int ssa_ctx_sync(ssa_ctx *ctx);
  * on.  Destroy it before the context; one that outlives its context is orphaned by ssa_ctx_destroy (its tables are
  * freed there, every call on it but ssa_keyset_destroy returns SSA_ERR_ARG), never a dangling pointer. */
 typedef struct ssa_keyset ssa_keyset;
-/* table kind: SSA_KEYSET_LADDER keeps eight multiples per key (2 KB; verification runs the 252-doubling ladder),
- * SSA_KEYSET_COMB a comb of [d * 2^(8w)]P, w < 32, d < 256 per key (768 KB; [h]P becomes 32 mixed additions, no
- * doublings -- about 5x less curve work per signature), SSA_KEYSET_AUTO the comb while all tables fit 4 GB */
+/* table kind: SSA_KEYSET_LADDER keeps sixteen multiples per key (4 KB; verification runs the 250-doubling ladder),
+ * SSA_KEYSET_COMB a comb of [d * 2^(16w)]P, w < 16, d < 65536 per key (100 MB; [h]P becomes 16 mixed additions, no
+ * doublings -- about 8x less curve work per signature), SSA_KEYSET_AUTO the comb while all tables fit 16 GB (160 keys) */
 #define SSA_KEYSET_AUTO 0u
 #define SSA_KEYSET_COMB 1u
 #define SSA_KEYSET_LADDER 2u

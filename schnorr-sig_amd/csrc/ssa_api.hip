@@ -720,18 +720,24 @@ extern "C" int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, cons
     }
     // few keys: a comb table per key (no doublings at verification time); many keys: the ladder tables only
     const size_t comb_bytes = m * KTAB_ENTRIES_PER_KEY * 12 * sizeof(u64);
-    ks->comb = flags == SSA_KEYSET_COMB || (flags == SSA_KEYSET_AUTO && comb_bytes <= ((size_t)4 << 30));
+    ks->comb = flags == SSA_KEYSET_COMB || (flags == SSA_KEYSET_AUTO && comb_bytes <= ((size_t)16 << 30));
     if (ks->comb) {
-        if (ks->ktab.reserve(comb_bytes)) {
+        DevBuf kbase;                                  // 768 KB per key, only while the combs are assembled
+        if (ks->ktab.reserve(comb_bytes) || kbase.reserve(m * KBASE_ENTRIES_PER_KEY * 12 * sizeof(u64))) {
+            kbase.release();
             ssa_keyset_destroy(ks);
             return SSA_ERR_HIP;
         }
         rc = timed_launch(ctx, "ssa_k_keycomb_build", [&] {
-            hipLaunchKernelGGL(ssa_k_keycomb_build, dim3(grid_for(m * KTAB_ENTRIES_PER_KEY, 256)), dim3(256), 0,
+            hipLaunchKernelGGL(ssa_k_keycomb_base, dim3(grid_for(m * KBASE_ENTRIES_PER_KEY, 256)), dim3(256), 0,
                                ctx->stream, (const u8 *)ks->pks.p, d_pk_inf, (const u8 *)ks->status.p, m,
-                               (u64 *)ks->ktab.p);
+                               (u64 *)kbase.p);
+            hipLaunchKernelGGL(ssa_k_keycomb_build, dim3(grid_for(m * (KTAB_ENTRIES_PER_KEY / 8), 256)), dim3(256), 0,
+                               ctx->stream, (const u64 *)kbase.p, m, (u64 *)ks->ktab.p);
         });
-        if (rc != 0 || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        const bool synced = hipStreamSynchronize(ctx->stream) == hipSuccess;
+        kbase.release();
+        if (rc != 0 || !synced) {
             ssa_keyset_destroy(ks);
             return rc ? rc : SSA_ERR_HIP;
         }

@@ -658,21 +658,26 @@ ssa_k_verify_keyed(const u8 *__restrict__ sigs, const u32 *__restrict__ key_idx,
 }
 #endif  // SSA_NO_KERNELS
 
-// Per-key comb (keyed context, few keys): ktab[key][w][d] = affine [d * 2^(8 w)] P_key, w < 32, d < 256 (768 KB per
-// key; identity entries -- d = 0, identity keys, multiples of small-order keys that vanish -- are the (0, 0)
-// sentinel).  [h]P is then 32 mixed additions and NO doublings: a signature costs 48 additions instead of 252
-// doublings + 79 additions.
-constexpr int KW_BITS = 8, KW_COUNT = 32;
+// Per-key comb (keyed context, few keys): ktab[key][w][d] = affine [d * 2^(16 w)] P_key, w < 16, d < 65536 (100 MB per
+// key -- round 4; 32 windows of 8 bits, 768 KB per key, before --; identity entries -- d = 0, identity keys, multiples of
+// small-order keys that vanish -- are the (0, 0) sentinel).  [h]P is then 16 mixed additions and NO doublings: a
+// signature costs 27 additions instead of 250 doublings + 62 additions.  Built like the comb for G: a base table
+// kbase[key][w'][d] = [d 2^(8 w')] P_key (w' < 32, d < 256: round 3's whole table) by double-and-add, then one affine
+// addition per entry -- exact for ANY key: a lane whose eight denominators include a zero (keys of small order: the two
+// parts can coincide or cancel) adds its entries with the complete Jacobian formulas instead.
+constexpr int KB_BITS = 8, KB_COUNT = 32;
+constexpr size_t KBASE_ENTRIES_PER_KEY = (size_t)KB_COUNT << KB_BITS;
+constexpr int KW_BITS = 16, KW_COUNT = 16;
 constexpr size_t KTAB_ENTRIES_PER_KEY = (size_t)KW_COUNT << KW_BITS;
 
 #ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
-ssa_k_keycomb_build(const u8 *__restrict__ pks, const u8 *__restrict__ pk_inf, const u8 *__restrict__ key_status,
-                    size_t m, u64 *__restrict__ ktab) {
+ssa_k_keycomb_base(const u8 *__restrict__ pks, const u8 *__restrict__ pk_inf, const u8 *__restrict__ key_status,
+                    size_t m, u64 *__restrict__ kbase) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m * KTAB_ENTRIES_PER_KEY) return;
-    const size_t key = t / KTAB_ENTRIES_PER_KEY;
-    const u32 w = (u32)((t >> KW_BITS) % KW_COUNT), d = (u32)(t & ((1u << KW_BITS) - 1u));
+    if (t >= m * KBASE_ENTRIES_PER_KEY) return;
+    const size_t key = t / KBASE_ENTRIES_PER_KEY;
+    const u32 w = (u32)((t >> KB_BITS) % KB_COUNT), d = (u32)(t & ((1u << KB_BITS) - 1u));
     aff a;
     a.x = f6_zero();
     a.y = f6_zero();
@@ -684,19 +689,73 @@ ssa_k_keycomb_build(const u8 *__restrict__ pks, const u8 *__restrict__ pk_inf, c
         P.y = ld_fp6(pks + 96 * key + 48, ok);
         jac acc = jac_identity();
 #pragma unroll 1
-        for (int b = KW_BITS - 1; b >= 0; b--) {
+        for (int b = KB_BITS - 1; b >= 0; b--) {
             acc = jac_dbl(acc);
             if ((d >> b) & 1u) acc = jac_madd(acc, P);
         }
 #pragma unroll 1
-        for (u32 k = 0; k < w * KW_BITS; k++) acc = jac_dbl(acc);
+        for (u32 k = 0; k < w * KB_BITS; k++) acc = jac_dbl(acc);
         a = jac_to_aff(acc);
     }
-    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(ktab + t * 12);
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(kbase + t * 12);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         q[i] = make_ulonglong2(a.x.c[2 * i], a.x.c[2 * i + 1]);
         q[3 + i] = make_ulonglong2(a.y.c[2 * i], a.y.c[2 * i + 1]);
+    }
+}
+
+// ktab[key][w][d] = kbase[key][2 w + 1][d >> 8] + kbase[key][2 w][d & 255]; a lane takes 8 consecutive entries
+__global__ void __launch_bounds__(256)
+ssa_k_keycomb_build(const u64 *__restrict__ kbase, size_t m, u64 *__restrict__ ktab) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * (KTAB_ENTRIES_PER_KEY / 8)) return;
+    const size_t key = t / (KTAB_ENTRIES_PER_KEY / 8), e0 = (t % (KTAB_ENTRIES_PER_KEY / 8)) * 8;
+    const u32 w = (u32)(e0 >> KW_BITS), d0 = (u32)(e0 & ((1u << KW_BITS) - 1u));
+    const u32 dhi = d0 >> KB_BITS, dlo0 = d0 & ((1u << KB_BITS) - 1u);
+    const u64 *kb = kbase + key * KBASE_ENTRIES_PER_KEY * 12;
+    const u64 *slo = kb + ((size_t)(2 * w) << KB_BITS) * 12, *shi = kb + ((size_t)(2 * w + 1) << KB_BITS) * 12;
+    u64 *out = ktab + (key * KTAB_ENTRIES_PER_KEY + e0) * 12;
+    const aff p1 = ld_aff(shi + (size_t)dhi * 12);
+    const bool p1_inf = f6_is_zero(p1.x) && f6_is_zero(p1.y);
+    if (p1_inf) {                                     // no high part (d_hi = 0, an identity key, a vanished multiple): copies
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) st_aff(out + 12 * k, ld_aff(slo + (size_t)(dlo0 + k) * 12));
+        return;
+    }
+    // forward: prefix products of the denominators x2 - x1 (1 for an identity low part), parked in the output rows
+    fp6 c = f6_one();
+    bool degenerate = false;
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        const aff p2 = ld_aff(slo + (size_t)(dlo0 + k) * 12);
+        const bool p2_inf = f6_is_zero(p2.x) && f6_is_zero(p2.y);
+        const fp6 a = p2_inf ? f6_one() : f6_sub(p2.x, p1.x);
+        degenerate = degenerate || f6_is_zero(a);
+        c = f6_mul(c, a);
+        st_f6(out + 12 * k, c);
+    }
+    if (degenerate) {                                 // P1 = +-P2 for some entry: the complete formulas for all eight
+#pragma unroll 1
+        for (int k = 0; k < 8; k++)
+            st_aff(out + 12 * k, jac_to_aff(jac_madd(jac_from_aff(p1), ld_aff(slo + (size_t)(dlo0 + k) * 12))));
+        return;
+    }
+    fp6 inv = f6_inv(c);
+#pragma unroll 1
+    for (int k = 7; k >= 0; k--) {
+        const aff p2 = ld_aff(slo + (size_t)(dlo0 + k) * 12);
+        const bool p2_inf = f6_is_zero(p2.x) && f6_is_zero(p2.y);
+        const fp6 a = p2_inf ? f6_one() : f6_sub(p2.x, p1.x);
+        fp6 ai = inv;
+        if (k > 0) ai = f6_mul(inv, ld_f6(out + 12 * (k - 1)));
+        inv = f6_mul(inv, a);
+        aff r = p1;
+        if (!p2_inf) r = aff_from_slope(f6_mul(f6_sub(p2.y, p1.y), ai), p1.x, p1.y, p2.x);
+        aff rc;
+        rc.x = f6_canon(r.x);
+        rc.y = f6_canon(r.y);
+        st_aff(out + 12 * k, rc);
     }
 }
 
@@ -726,13 +785,8 @@ ssa_k_verify_keyed_comb(const u8 *__restrict__ sigs, const u32 *__restrict__ key
             for (int j = 0; j < 4; j++) h.w[j] = h_in[4 * i + j];
             jac r = jac_identity();
 #pragma unroll 1
-            for (int w = 0; w < KW_COUNT; w++) {          // [h]P: one mixed addition per non-zero byte of h
-                const u32 wi = (u32)w >> 3;
-                u64 word = h.w[0];
-                if (wi == 1) word = h.w[1];
-                if (wi == 2) word = h.w[2];
-                if (wi == 3) word = h.w[3];
-                const u32 d = (u32)(word >> ((w & 7) * 8)) & 0xffu;
+            for (int w = 0; w < KW_COUNT; w++) {          // [h]P: one mixed addition per non-zero 16-bit window of h
+                const u32 d = sc_bits(h, (u32)w * (u32)KW_BITS, (u32)KW_BITS);
                 if (d != 0) r = jac_madd_fast(r, ld_aff(tab + (((size_t)w << KW_BITS) + d) * 12));
             }
             r = add_base_mul(r, gtab, e);

@@ -79,6 +79,8 @@ while time.time() - t0 < budget:
         # keyed context, both table kinds (every signature its own key here)
         if n <= 2000:
             for kind in ("ladder", "comb"):
+                if kind == "comb" and n > 150:          # 100 MB of comb per key since round 4
+                    continue
                 ks = eng.keyset_create(pks, pk_inf=inf, kind=kind)
                 st, nf = eng.verify_many_indexed(ks, np.arange(n, dtype=np.uint32), sigs, flat, offsets=off,
                                                  check_torsion=torsion, sig_flag_byte=fb)
