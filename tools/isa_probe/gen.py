@@ -155,6 +155,73 @@ probe("cmp64_cndmask_lshladd", ["v_lshl_add_u64 v[20:21], v[10:11], 0, v[12:13]"
 probe("ds_read_b128_plus_4add", ["ds_read_b128 v[{q}:{q3}], v18", "v_add_u32 v36, v10, v11", "v_add_u32 v37, v10, v11", "v_add_u32 v38, v10, v12", "v_add_u32 v39, v10, v12"], n_instr=5, setup="lds")
 
 
+# ---- round 4 (second session): one Fp6 coefficient's accumulation (6 products = 24 multiply-adds on three 64-bit columns, a
+# carry per multiply) + a stand-in for its reduction.  coef_valu: every carry by v_addc (the shipped form, 59 VALU).
+# coef_salu_c1: the 12 carries of the middle column counted on the SCALAR unit instead (bit-sliced counter planes P1, P2,
+# P4, P8 in SGPR pairs, full-adder steps interleaved with the next product's multiplies), converted to a VGPR count by
+# 4 v_cndmask + 2 adds: 53 VALU + 47 SALU.  Does the scalar unit take the work for free (other wave's issue slot)?
+def _reduction_standin():
+    return ["v_add_co_u32 v27, s[52:53], v27, v28", "v_addc_co_u32 v29, s[52:53], v29, v30, s[52:53]",
+            "v_add_co_u32 v29, s[54:55], v29, v36", "v_addc_co_u32 v31, s[52:53], v31, v37, s[52:53]",
+            "v_addc_co_u32 v31, s[54:55], 0, v31, s[54:55]", "v_addc_co_u32 v38, s[52:53], 0, v38, s[52:53]",
+            "v_addc_co_u32 v38, s[54:55], 0, v38, s[54:55]",
+            "v_mad_u64_u32 v[32:33], s[52:53], v29, -1, v[26:27]", "v_subb_co_u32 v32, s[54:55], v32, v31, s[52:53]",
+            "v_subbrev_co_u32 v34, s[56:57], 0, v38, s[52:53]", "v_subb_co_u32 v33, s[54:55], v33, v34, s[54:55]"]
+
+
+def _coef_valu():
+    out = []
+    for i in range(6):
+        out += ["v_mad_u64_u32 v[28:29], vcc, v10, v13, v[28:29]", "v_mad_u64_u32 v[26:27], s[40:41], v10, v12, v[26:27]",
+                "v_mad_u64_u32 v[28:29], s[44:45], v11, v12, v[28:29]", "v_mad_u64_u32 v[30:31], s[42:43], v11, v13, v[30:31]",
+                "v_addc_co_u32 v37, vcc, 0, v37, vcc", "v_addc_co_u32 v36, s[40:41], 0, v36, s[40:41]",
+                "v_addc_co_u32 v37, s[44:45], 0, v37, s[44:45]", "v_addc_co_u32 v38, s[42:43], 0, v38, s[42:43]"]
+    return out + _reduction_standin()
+
+
+def _coef_salu():
+    out = []
+    P1, P2, P4, P8 = "s[46:47]", "s[48:49]", "s[50:51]", "s[58:59]"
+    T, M, U, C, D, E = "s[38:39]", "s[52:53]", "s[54:55]", "s[56:57]", "s[52:53]", "s[54:55]"
+
+    def salu(i):       # fold the two middle-column carries of product i into the counter planes
+        a, b = ("s[40:41]", "s[42:43]") if i % 2 == 0 else ("s[44:45]", "vcc")
+        if i == 0:
+            return ["s_xor_b64 %s, %s, %s" % (P1, a, b), "s_and_b64 %s, %s, %s" % (P2, a, b)]
+        ops = ["s_xor_b64 %s, %s, %s" % (T, a, b), "s_and_b64 %s, %s, %s" % (M, a, b), "s_and_b64 %s, %s, %s" % (U, P1, T),
+               "s_xor_b64 %s, %s, %s" % (P1, P1, T), "s_or_b64 %s, %s, %s" % (C, M, U)]
+        if i == 1:
+            return ops + ["s_and_b64 %s, %s, %s" % (P4, P2, C), "s_xor_b64 %s, %s, %s" % (P2, P2, C)]
+        ops += ["s_and_b64 %s, %s, %s" % (D, P2, C), "s_xor_b64 %s, %s, %s" % (P2, P2, C)]
+        if i == 2:
+            return ops + ["s_xor_b64 %s, %s, %s" % (P4, P4, D)]
+        if i == 3:
+            return ops + ["s_and_b64 %s, %s, %s" % (P8, P4, D), "s_xor_b64 %s, %s, %s" % (P4, P4, D)]
+        return ops + ["s_and_b64 %s, %s, %s" % (E, P4, D), "s_xor_b64 %s, %s, %s" % (P4, P4, D), "s_xor_b64 %s, %s, %s" % (P8, P8, E)]
+
+    pend = []
+    for i in range(6):
+        a, b = ("s[40:41]", "s[42:43]") if i % 2 == 0 else ("s[44:45]", "vcc")
+        valu = ["v_mad_u64_u32 v[28:29], %s, v10, v13, v[28:29]" % a, "v_mad_u64_u32 v[26:27], s[60:61], v10, v12, v[26:27]",
+                "v_mad_u64_u32 v[28:29], %s, v11, v12, v[28:29]" % b, "v_mad_u64_u32 v[30:31], s[62:63], v11, v13, v[30:31]",
+                "v_addc_co_u32 v36, s[60:61], 0, v36, s[60:61]", "v_addc_co_u32 v38, s[62:63], 0, v38, s[62:63]"]
+        # interleave the scalar work of the PREVIOUS product between this product's vector instructions
+        for j, v in enumerate(valu):
+            out.append(v)
+            take = (len(pend) + (len(valu) - j) - 1) // (len(valu) - j)
+            out += pend[:take]
+            pend = pend[take:]
+        pend = salu(i)
+    out += pend
+    out += ["v_cndmask_b32 v37, 0, 1, %s" % P1, "v_cndmask_b32 v34, 0, 2, %s" % P2, "v_cndmask_b32 v35, 0, 4, %s" % P4,
+            "v_cndmask_b32 v39, 0, 8, %s" % P8, "v_add3_u32 v37, v37, v34, v35", "v_add_u32 v37, v37, v39"]
+    return out + _reduction_standin()
+
+
+probe("coef_valu", _coef_valu(), n_instr=59)
+probe("coef_salu_c1", _coef_salu(), n_instr=59)        # reported per instruction of the SHIPPED form: directly comparable
+
+
 def body(pattern):
     lines = []
     for i in range(R):
