@@ -57,6 +57,12 @@ def regs(c):
 MOVES_HEAD = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "carries"       # "moves" (default), "moves10", "carries"
 SQ_MERGE_FAST = os.environ.get("SSA_GEN_SQ_MERGE", "") == "fast"
 MUL_HEAD_ADD1 = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "moves10"     # round 4 default; "moves10" = round 3's head
+# Squarings per loop iteration inside the S-box programs; 0 (default since round 4) = no loops at all: the 58 squarings of the
+# five `square n times` runs are emitted straight (1652 VALU instructions, 13 KB: the instruction cache holds them).  The
+# three scalar instructions and the taken branch per iteration were not free even at four waves per SIMD: ssa_k_hash
+# 8.35 / 8.36 / 8.25 ms with loops against 8.20 / 8.14 / 8.16 ms without, same box, alternating (unrolling by 2 or 4: no
+# gain) -- profiles/r04/hash_ab.txt (e).
+SQ_UNROLL = int(os.environ.get("SSA_GEN_SQ_UNROLL", "0"))
 DUMMY = "s[24:25]"     # carry-outs nobody reads
 STICKY = 40            # s[40:41] / s[42:43]: lanes of chain 0 / 1 whose reduction met the rare borrow (see the docstring)
 SGPRS = list(range(20, 32)) + list(range(36, 44))
@@ -209,14 +215,15 @@ def emit_program(name, prog, doc):
     for op in prog:
         if op[0] == "sq":
             n = op[1]
-            if n <= 2:
+            u = SQ_UNROLL if SQ_UNROLL > 0 else n
+            if n <= 2 or n // u < 2:
                 seg = sq_body * n
                 body += seg
             else:
                 lab = "L_%s_%%=_%d" % (name, n_loop)
                 n_loop += 1
-                body += ["s_mov_b32 s26, %d" % n, lab + ":"] + sq_body + ["s_sub_u32 s26, s26, 1", "s_cmp_lg_u32 s26, 0",
-                                                                          "s_cbranch_scc1 " + lab]
+                body += ["s_mov_b32 s26, %d" % (n // u), lab + ":"] + sq_body * u + \
+                    ["s_sub_u32 s26, s26, 1", "s_cmp_lg_u32 s26, 0", "s_cbranch_scc1 " + lab] + sq_body * (n % u)
             counts["valu"] += n * sum(1 for ln in sq_body if ln.startswith("v_"))
             counts["nop"] += n * sum(1 for ln in sq_body if ln.startswith("s_nop"))
         else:
