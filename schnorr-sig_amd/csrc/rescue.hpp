@@ -51,39 +51,64 @@ SSA_DEV u64 inv_sbox(u64 x) {
 }
 
 // Two state elements at a time, the whole chain of both in ONE asm block (fp_chain_asm.inc,
-// tools/gen_fp_chain_asm.py): 11 instructions per squaring and 15 per product instead of hipcc's 22-26 + s_nop
-// padding, the two values interleaved by a list scheduler so that the SGPR carries get their wait states.
+// tools/gen_fp_chain_asm.py): 11 instructions per squaring and 13 per product instead of hipcc's 22-26 + s_nop
+// padding, the two values interleaved by a list scheduler so that the SGPR carries get their wait states; the values are
+// pinned to the blocks' own registers (no moves in or out) and the chain's "copies" are register renamings.
 // The blocks do not repair the one rare event of their reduction (a borrow with probability ~2^-32 per squaring, see
-// the generator): they REPORT the lanes that met it and hand those lanes their inputs back, and the lanes are
-// recomputed with the compiled, exact chain.  ~1 lane in 3 * 10^5 hashes takes that branch.
+// the generator): they OR the lanes that met it into a wave-wide mask.  The caller tests the mask on the scalar unit
+// (one compare and one branch per block, no vector instruction) and recomputes the S-boxes of a flagged lane -- about one
+// lane in 3 * 10^5 hashes -- from its inputs, which are still in the LDS state, with the compiled exact chain.
+// (A first form of this round re-hashed a flagged lane from scratch at the END of its hash: fewer instructions still, but
+// a 2^20-signature launch has ~3 such lanes and a wave that hashes twice in the last wave generation holds the whole
+// kernel back: 8.44 instead of 8.12 ms.)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SSA_NO_FP_CHAIN_ASM)
+#define SSA_FP_CHAIN_ASM 1
 #ifdef SSA_FP_CHAIN_INC          // an alternative generated file (A/B builds: tools/build_variants.sh)
 #include SSA_FP_CHAIN_INC
 #else
 #include "fp_chain_asm.inc"
 #endif
-SSA_DEV void inv_sbox2(u64 &x, u64 &y) {
-    if (inv_sbox2_asm(x, y)) {      // flagged lanes get their inputs back (no copy is kept alive across the block)
-        x = inv_sbox(x);
-        y = inv_sbox(y);
-    }
-}
-SSA_DEV void sbox2(u64 &x, u64 &y) {
-    if (sbox2_asm(x, y)) {
-        x = sbox(x);
-        y = sbox(y);
-    }
-}
-#else
-SSA_DEV void inv_sbox2(u64 &x, u64 &y) {
-    x = inv_sbox(x);
-    y = inv_sbox(y);
-}
-SSA_DEV void sbox2(u64 &x, u64 &y) {
-    x = sbox(x);
-    y = sbox(y);
+// this lane's bit of a wave-wide mask
+SSA_DEV bool lane_bit(u64 mask) {
+    const u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return ((mask >> lane) & 1ull) != 0;
 }
 #endif
+// x <- x^(1/7), y <- y^(1/7) for the state elements at px, py (read here, written back by the caller)
+SSA_DEV void inv_sbox2(const u64 *px, const u64 *py, u64 &x, u64 &y) {
+    x = *px;
+    y = *py;
+#ifdef SSA_FP_CHAIN_ASM
+    u64 st = 0;
+    inv_sbox2_asm(x, y, st);
+    if (st != 0) {                 // wave-uniform: some lane of the wave met the rare borrow
+        if (lane_bit(st)) {
+            x = inv_sbox(*px);
+            y = inv_sbox(*py);
+        }
+    }
+#else
+    x = inv_sbox(x);
+    y = inv_sbox(y);
+#endif
+}
+SSA_DEV void sbox2(const u64 *px, const u64 *py, u64 &x, u64 &y) {
+    x = *px;
+    y = *py;
+#ifdef SSA_FP_CHAIN_ASM
+    u64 st = 0;
+    sbox2_asm(x, y, st);
+    if (st != 0) {
+        if (lane_bit(st)) {
+            x = sbox(*px);
+            y = sbox(*py);
+        }
+    }
+#else
+    x = sbox(x);
+    y = sbox(y);
+#endif
+}
 
 // The 12-felt sponge state of a lane lives in LDS ("LDS-staged"): element i of lane t is
 // st[i * RS_STRIDE + t], so dynamic indexing costs a ds_read/ds_write instead of forcing the
@@ -160,8 +185,8 @@ SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ pr
     for (u32 r = 0; r < nr; r++) {
 #pragma unroll 1
         for (int i = 0; i < 6; i++) {  // two independent chains per iteration
-            u64 x = A[i * RS_STRIDE], y = A[(i + 6) * RS_STRIDE];
-            sbox2(x, y);
+            u64 x, y;
+            sbox2(A + i * RS_STRIDE, A + (i + 6) * RS_STRIDE, x, y);
             A[i * RS_STRIDE] = x;
             A[(i + 6) * RS_STRIDE] = y;
         }
@@ -170,8 +195,8 @@ SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ pr
         else mds_ark<false>(A, B, prm->mds, prm->ark1 + 12 * r);
 #pragma unroll 1
         for (int i = 0; i < 6; i++) {
-            u64 x = B[i * RS_STRIDE], y = B[(i + 6) * RS_STRIDE];
-            inv_sbox2(x, y);
+            u64 x, y;
+            inv_sbox2(B + i * RS_STRIDE, B + (i + 6) * RS_STRIDE, x, y);
             B[i * RS_STRIDE] = x;
             B[(i + 6) * RS_STRIDE] = y;
         }

@@ -1151,26 +1151,27 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
         return;
     }
     if (op == 18) {   // the Rescue S-boxes on RAW loose values: a = (x, y) -> x^7, y^7, x^(1/7), y^(1/7), asm flags
-        u64 x = pa[0], y = pa[1];
-        sbox2(x, y);
+        // po[0..3]: the product's wrappers (asm block, then the compiled exact chain for a lane the block flagged);
+        // po[4], po[5]: this lane's bit of the mask sbox2_asm / inv_sbox2_asm collect
+        u64 x, y;
+        sbox2(pa, pa + 1, x, y);
         po[0] = fp_canon(x);
         po[1] = fp_canon(y);
-        x = pa[0];
-        y = pa[1];
-        inv_sbox2(x, y);
+        inv_sbox2(pa, pa + 1, x, y);
         po[2] = fp_canon(x);
         po[3] = fp_canon(y);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SSA_NO_FP_CHAIN_ASM)
-        x = pa[0];
-        y = pa[1];
-        po[4] = sbox2_asm(x, y);          // non-zero: this lane's reduction met the rare borrow (the wrappers above
-        if (po[4] && (x != pa[0] || y != pa[1])) po[4] = 0xbad;   //   recomputed it); the inputs must come back
-        x = pa[0];
-        y = pa[1];
-        po[5] = inv_sbox2_asm(x, y);
-        if (po[5] && (x != pa[0] || y != pa[1])) po[5] = 0xbad;
-#else
         po[4] = po[5] = 0;
+#ifdef SSA_FP_CHAIN_ASM
+        u64 st = 0;
+        x = pa[0];
+        y = pa[1];
+        sbox2_asm(x, y, st);
+        po[4] = lane_bit(st) ? 1u : 0u;
+        st = 0;
+        x = pa[0];
+        y = pa[1];
+        inv_sbox2_asm(x, y, st);
+        po[5] = lane_bit(st) ? 1u : 0u;
 #endif
         return;
     }

@@ -74,7 +74,9 @@ class Lane:
 
     def _key(self, o):
         o = o.strip()
-        return "vcc" if o == "vcc" else int(re.match(r"s\[(\d+):(\d+)\]$", o).group(1))
+        if o == "vcc" or o.startswith("%["):        # %[name]: an SGPR-pair operand of the statement (a mask the caller owns)
+            return o
+        return int(re.match(r"s\[(\d+):(\d+)\]$", o).group(1))
 
     def wc(self, o, bit):
         k = self._key(o)

@@ -15,18 +15,28 @@ INC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 import asm_interp as ai
 
 F6_INC = os.path.join(os.path.dirname(INC), "fp6_asm.inc")
 
 
 def run(txt_blocks, fn, x, y):
-    """-> (x', y', flag): flag != 0 means a reduction met its rare borrow and x', y' are to be recomputed"""
+    """-> (x', y', flag): flag != 0 means a reduction met its rare borrow and x', y' are to be recomputed.
+    fp_sqr2_n_asm takes its values as named operands and returns a per-lane flag; the two S-box programs have their values
+    PINNED to the chains' value registers and OR the flagged lanes into the mask operand %[st]."""
     lines, outs, _ = txt_blocks[fn]
-    env = {"%[x0]": x & M32, "%[x1]": x >> 32, "%[y0]": y & M32, "%[y1]": y >> 32, "%[n]": 5}
-    lane = ai.Lane(env, dummy_pairs=("s[24:25]",))
-    e = lane.run(lines)
-    return e["%[x0]"] | (e["%[x1]"] << 32), e["%[y0]"] | (e["%[y1]"] << 32), e["%[fl]"]
+    if fn == "fp_sqr2_n_asm":
+        env = {"%[x0]": x & M32, "%[x1]": x >> 32, "%[y0]": y & M32, "%[y1]": y >> 32, "%[n]": 5}
+        lane = ai.Lane(env, dummy_pairs=("s[24:25]",))
+        e = lane.run(lines)
+        return e["%[x0]"] | (e["%[x1]"] << 32), e["%[y0]"] | (e["%[y1]"] << 32), e["%[fl]"]
+    import gen_fp_chain_asm as g
+    rx, ry = g.regs(0)["X"], g.regs(1)["X"]
+    lane = ai.Lane({}, dummy_pairs=("s[24:25]",))
+    lane.v[rx], lane.v[rx + 1], lane.v[ry], lane.v[ry + 1] = x & M32, x >> 32, y & M32, y >> 32
+    lane.run(lines)
+    return lane.v[rx] | (lane.v[rx + 1] << 32), lane.v[ry] | (lane.v[ry + 1] << 32), lane.s.get("%[st]", 0)
 
 
 def test_generated_sbox_asm_on_the_cpu():
@@ -47,18 +57,29 @@ def test_generated_sbox_asm_on_the_cpu():
     assert flagged <= 6          # only the hand-picked edge values can get there (2^32 * 2^32 = 2^64, ...)
 
 
+def test_sbox_programs_execute_no_copy_and_no_loop():
+    """round 4: the chains' `cp` steps are register renamings and the squaring runs are straight code; the statement has no
+    move in or out (values pinned), so its VALU count is the arithmetic's: 63 squarings x 11 + 9 products x 13 per value"""
+    txt = ai.extract_blocks(INC)
+    for fn, n_sq, n_mul in (("inv_sbox2_asm", 63, 9), ("sbox2_asm", 2, 2)):
+        lines = txt[fn][0]
+        valu = [ln for ln in lines if ln.startswith("v_")]
+        assert len(valu) == 2 * (11 * n_sq + 13 * n_mul) + 2, (fn, len(valu))       # + the two zero high words
+        assert not any(ln.startswith(("s_cbranch", "s_branch")) or ln.endswith(":") for ln in lines), fn
+        movs = [ln for ln in valu if ln.startswith("v_mov_b32")]
+        assert len(movs) == 2 + 2 * 4 * n_mul, (fn, len(movs))                      # only the product head's four word moves
+
+
 def test_sbox_asm_reports_the_rare_borrow():
     """a = k 2^48: a^2 = k^2 2^96, so lo = 0, hi.lo = 0, hi.hi = k^2 -- the reduction X - h1 borrows with no carry to
-    cancel it.  The block must flag such a lane (in either chain) instead of returning a wrong value, and must not
-    flag the neighbour chain's lane-mate for it... it does: the flag is per lane, for both values."""
+    cancel it.  The block must flag such a lane (in either chain) instead of passing a wrong value on silently: the S-box
+    programs OR it into their mask operand (the caller re-hashes the lane), fp_sqr2_n_asm returns it."""
     txt = ai.extract_blocks(INC)
     for k in (1, 3, 0xffff):
         a = k << 48
         for fn in ("inv_sbox2_asm", "sbox2_asm", "fp_sqr2_n_asm"):
             assert run(txt, fn, a, 5)[2] == 1 and run(txt, fn, 5, a)[2] == 1, (fn, k)
             assert run(txt, fn, 5, 7)[2] == 0
-        for fn in ("inv_sbox2_asm", "sbox2_asm"):     # a flagged lane gets its inputs back: the caller recomputes from them
-            assert run(txt, fn, a, 5) == (a, 5, 1) and run(txt, fn, 6, a) == (6, a, 1), (fn, k)
 
 
 def test_reduction_tail_is_exact_or_flagged():
@@ -233,6 +254,11 @@ def test_asm_blocks_declare_what_they_clobber():
         for m in re.finditer(r"SSA_DEV (?:void|u32) (\w+)\(.*?asm(?: volatile)?\(\n(.*?)\n        : (.*?)\n        :(.*?)\n        : (\".*?)\);", txt, re.S):
             name, body, clob = m.group(1), m.group(2), m.group(5)
             clobbers = set(re.findall(r'"(\w+)"', clob))
+            # registers an operand is PINNED to ("+{v[72:73]}"(x)) are declared by the operand, and must not be clobbers too
+            for lo, hi in re.findall(r'"[=+]&?\{v\[(\d+):(\d+)\]\}"', m.group(3) + m.group(4)):
+                for r in range(int(lo), int(hi) + 1):
+                    assert "v%d" % r not in clobbers, (name, r)
+                    clobbers.add("v%d" % r)
             if re.search(r'"s_(andn2|and|xor|or|sub|add|cmp)', body):
                 assert "scc" in clobbers, name
             for reg in set(re.findall(r"\bv(\d+)\b", body)):

@@ -76,17 +76,21 @@ def sp(r):
     return "s[%d:%d]" % (r, r + 1)
 
 
-def square(c):
-    """(text, sgprs read, sgprs written) of one squaring of chain c, in dependency order"""
+def square(c, src=None, dst=None, st=None):
+    """(text, sgprs read, sgprs written) of one squaring of chain c, in dependency order.  src / dst: the register pairs
+    the value is read from and written to (default: in place in X); st: the asm operand that collects the rare-borrow
+    lanes (default: the chain's own sticky pair)"""
     g = regs(c)
     X, T, A, U, H, R, M, E, C, S = (g[k] for k in "XTAUHRMECS")
+    XS = X if src is None else src          # the three products read the source pair ...
+    X = X if dst is None else dst           # ... the reduction writes the destination pair
     S2 = S + 8            # second carry pair of the chain: s[28:29] / s[30:31]
     S3 = S + 16           # scratch mask: s[36:37] / s[38:39] (s32 / s33 are the stack and frame pointers)
     s = sp(S)
     return [
-        ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, X), [], []),
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, XS, XS), [], []),
         ("v_lshrrev_b32 v%d, 1, v%d" % (A, T + 1), [], []),                       # (t0 >> 33); v[A+1] stays 0
-        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), DUMMY, X, X + 1, vp(A)), [], []),
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(U), DUMMY, XS, XS + 1, vp(A)), [], []),
         ("v_and_b32 v%d, 1, v%d" % (T + 1, T + 1), [], []),
         ("v_lshrrev_b64 %s, 31, %s" % (vp(H), vp(U)), [], []),
     ] + ([
@@ -98,7 +102,7 @@ def square(c):
         ("v_add_u32 v%d, v%d, v%d" % (M, U, U), [], []),                          # (u.lo << 1) mod 2^32
         ("v_or_b32 v%d, v%d, v%d" % (T + 1, M, T + 1), [], []),
     ]) + [
-        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, X + 1, vp(H)), [], []),   # hi
+        ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, XS + 1, XS + 1, vp(H)), [], []),   # hi
         # reduction (see the module docstring): X = EPS * h0 + lo (carry c -> s2), then X + c EPS - h1 as one 64-bit
         # subtraction with borrow-in c; a final borrow while c = 0 is the rare "+ p" case: sticky, repaired by the caller
         ("v_mad_u64_u32 %s, %s, v%d, -1, %s" % (vp(X), sp(S2), H, vp(T)), [], [S2]),
@@ -106,22 +110,24 @@ def square(c):
         ("v_cndmask_b32 v%d, 0, -1, %s" % (E, sp(S2)), [], []),                                       # c ? 0xffffffff : 0
         ("v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (X + 1, sp(S3), X + 1, E, s), [], [S3]),             # X.hi + c - borrow
         ("s_andn2_b64 %s, %s, %s" % (sp(S3), sp(S3), sp(S2)), [], []),                                # borrow and not c
-        ("s_or_b64 %s, %s, %s" % (sp(STICKY + 2 * c), sp(STICKY + 2 * c), sp(S3)), [], []),
+        ("s_or_b64 %s, %s, %s" % ((sp(STICKY + 2 * c),) * 2 + (sp(S3),) if st is None else (st, st, sp(S3))), [], []),
     ]
 
 
-def reduce_tail(c):
-    """lo = v[T:T+1], hi = v[H:H+1] -> X (the last six instructions of square())"""
-    return square(c)[7:]      # from the multiply-add by EPS on
+def reduce_tail(c, dst=None, st=None):
+    """lo = v[T:T+1], hi = v[H:H+1] -> X or dst (the last six instructions of square())"""
+    return square(c, None, dst, st)[7:]      # from the multiply-add by EPS on
 
 
-def multiply(c, saved):
+def multiply(c, saved, src=None, dst=None, st=None):
     """X <- X * saved value (register pair name "V0".."V4"): four multiplies, operand-scanning with the addends in
     zero-extended pairs (v[A+1] and v[C+1] hold 0), then the reduction.  The alternative below the early return -- the
     65-bit middle sum's carry k riding into the top product as the addend (0, k), a three-instruction carry chain for the
     halves: 8 instructions instead of 10 -- measured slower (see MOVES_HEAD)."""
     g = regs(c)
-    X, T, A, U, H, C, E, V, S = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved], g["S"]
+    X, T, A, U, H, C, E, V, S = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved] if isinstance(saved, str) else saved, g["S"]
+    if src is not None:
+        X = src                 # the head reads the source pair; the reduction writes dst (reduce_tail)
     S2, S3 = S + 8, S + 16
     if MOVES_HEAD and not MUL_HEAD_ADD1:        # round 3's head: 10 instructions
         return [
@@ -135,7 +141,7 @@ def multiply(c, saved):
             ("v_mov_b32 v%d, v%d" % (C, H + 1), [], []),
             ("v_lshl_add_u64 %s, %s, 0, %s" % (vp(E), vp(A), vp(C)), [], []),       # v[A+1], v[C+1] hold 0
             ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V + 1, vp(E)), [], []),
-        ] + reduce_tail(c)
+        ] + reduce_tail(c, dst, st)
     if MOVES_HEAD:
         # round 4: NINE instructions.  The high word of the second cross product joins the top product through a
         # multiply-add by the inline constant 1 (S0 may be any VGPR, so no zero-extended pair has to be built for it):
@@ -152,7 +158,7 @@ def multiply(c, saved):
             ("v_mov_b32 v%d, v%d" % (A, U + 1), [], []),
             ("v_mad_u64_u32 %s, %s, v%d, v%d, %s" % (vp(H), DUMMY, X + 1, V + 1, vp(A)), [], []),  # x1 s1 + t1.hi
             ("v_mad_u64_u32 %s, %s, v%d, 1, %s" % (vp(H), DUMMY, M + 1, vp(H)), [], []),           # + t2.hi
-        ] + reduce_tail(c)
+        ] + reduce_tail(c, dst, st)
     head = [
         ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),                   # t0 = x0 s0
         ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(U), DUMMY, X, V + 1), [], []),               # x0 s1
@@ -163,7 +169,7 @@ def multiply(c, saved):
         ("v_addc_co_u32 v%d, %s, v%d, v%d, %s" % (H, sp(S3), H, U + 1, sp(S2)), [], [S3]),      # hi.lo = t3.lo + mid.hi + carry
         ("v_addc_co_u32 v%d, %s, 0, v%d, %s" % (H + 1, sp(S2), H + 1, sp(S3)), [], [S2]),       # hi.hi += carry (cannot overflow)
     ]
-    return head + reduce_tail(c)
+    return head + reduce_tail(c, dst, st)
 
 
 def zero_inits(g):
@@ -198,58 +204,90 @@ STICKY_OUT = ["s_or_b64 %s, %s, %s" % (sp(STICKY), sp(STICKY), sp(STICKY + 2)), 
               "v_cndmask_b32 %%[fl], 0, 1, %s" % sp(STICKY)]
 
 
+VALUE_PAIRS = ["X", "V0", "V1", "V2", "V3", "V4"]     # the six pairs a chain's values live in (the roles move: see rename)
+
+
+def rename(prog):
+    """The programs say `cp V, X` / `cp X, V`; no copy is ever executed (round 4).  Every squaring and product reads its
+    source pair in its first instructions and writes its result with its last three, so the result can go to ANY free pair:
+    a copy is a second name for the pair the value is in, and the next operation writes somewhere else.  Returns
+    [(op, operand index or None, source index, destination index)] over indices into VALUE_PAIRS' registers; the input
+    arrives in pair 0 and the result is steered back into pair 0 (the pinned in/out operand of the asm statement)."""
+    # names read after op i (a later `cp V, X` re-defines V: its old pair is dead from its last use on)
+    live_after, live = [None] * len(prog), set()
+    for i in range(len(prog) - 1, -1, -1):
+        live_after[i] = set(live)
+        op = prog[i]
+        if op[0] == "mul":
+            live.add(op[1])
+        elif op[0] == "cp" and op[2] == "X":
+            live.discard(op[1])
+        elif op[0] == "cp" and op[1] == "X":
+            live.add(op[2])
+    idx, out = {"X": 0}, []
+    n_ops = sum(op[1] if op[0] == "sq" else 1 for op in prog if op[0] != "cp")
+    done = 0
+    for i, op in enumerate(prog):
+        if op[0] == "cp":
+            if op[1] == "X":
+                idx["X"] = idx[op[2]]
+            else:
+                idx[op[1]] = idx["X"]
+            continue
+        for k in range(op[1] if op[0] == "sq" else 1):
+            last_of_op = op[0] != "sq" or k == op[1] - 1
+            # pairs that hold a value somebody still needs: names live after this operation (while a run of squarings is
+            # in progress, the names live after the whole run)
+            busy = {idx[nm] for nm in live_after[i] if nm in idx}
+            v = idx[op[1]] if op[0] == "mul" else None
+            src = idx["X"]
+            done += 1
+            if done == n_ops:
+                dst = 0                         # the result leaves in the pair the input came in
+                assert 0 not in busy
+            elif src not in busy:
+                dst = src                       # in place
+            else:
+                dst = min(j for j in range(len(VALUE_PAIRS)) if j not in busy and j != src and j != v)
+            out.append((op[0], v, src, dst))
+            idx["X"] = dst
+            del last_of_op
+    return out
+
+
 def emit_program(name, prog, doc):
     g0, g1 = regs(0), regs(1)
     lines = ["// %s" % doc,
-             "// returns non-zero in the lanes where a reduction met its rare borrow: x and y then come back UNCHANGED and the",
-             "// caller recomputes them with the compiled exact code",
-             "SSA_DEV u32 %s(u64 &x, u64 &y) {" % name,
-             "    u32 x0 = lo32(x), x1 = hi32(x), y0 = lo32(y), y1 = hi32(y), fl;", "    asm volatile("]
-    body = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
-                          "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
+             "// x and y are pinned to the blocks' own value registers (no moves in or out; the compiler loads the state",
+             "// straight into them); st collects the lanes (bit per lane) where a reduction met its rare borrow: their x and y are",
+             "// then WRONG and the caller recomputes the whole hash of such a lane with the compiled exact code (rescue.hpp)",
+             "SSA_DEV void %s(u64 &x, u64 &y, u64 &st) {" % name, "    asm volatile("]
+    body = []
     for g in (g0, g1):
         body += zero_inits(g)
-    n_loop = 0
     counts = {"valu": 0, "nop": 0}
-    sq_body = schedule([square(0), square(1)])
-    for op in prog:
-        if op[0] == "sq":
-            n = op[1]
-            u = SQ_UNROLL if SQ_UNROLL > 0 else n
-            if n <= 2 or n // u < 2:
-                seg = sq_body * n
-                body += seg
+    for kind, v, src, dst in rename(prog):
+        chains = []
+        for c, g in ((0, g0), (1, g1)):
+            pr = [g[nm] for nm in VALUE_PAIRS]
+            if kind == "sq":
+                chains.append(square(c, pr[src], pr[dst], "%[st]"))
             else:
-                lab = "L_%s_%%=_%d" % (name, n_loop)
-                n_loop += 1
-                body += ["s_mov_b32 s26, %d" % (n // u), lab + ":"] + sq_body * u + \
-                    ["s_sub_u32 s26, s26, 1", "s_cmp_lg_u32 s26, 0", "s_cbranch_scc1 " + lab] + sq_body * (n % u)
-            counts["valu"] += n * sum(1 for ln in sq_body if ln.startswith("v_"))
-            counts["nop"] += n * sum(1 for ln in sq_body if ln.startswith("s_nop"))
-        else:
-            if op[0] == "mul":
-                seg = schedule([multiply(0, op[1]), multiply(1, op[1])])
-            else:
-                seg = schedule([copy(0, op[1], op[2]), copy(1, op[1], op[2])])
-            body += seg
-            counts["valu"] += sum(1 for ln in seg if ln.startswith("v_"))
-            counts["nop"] += sum(1 for ln in seg if ln.startswith("s_nop"))
-    # results out -- or, in a flagged lane, the INPUTS back (V0 still holds them: both programs save x there first
-    # and never overwrite it), so that the caller recomputes from x, y themselves and keeps no copy alive across the block
-    assert prog[0] == ("cp", "V0", "X") and not any(op[0] == "cp" and op[1] == "V0" for op in prog[1:])
-    body += STICKY_OUT[:2] + \
-        ["v_cndmask_b32 %%[x0], v%d, v%d, %s" % (g0["X"], g0["V0"], sp(STICKY)),
-         "v_cndmask_b32 %%[x1], v%d, v%d, %s" % (g0["X"] + 1, g0["V0"] + 1, sp(STICKY)),
-         "v_cndmask_b32 %%[y0], v%d, v%d, %s" % (g1["X"], g1["V0"], sp(STICKY)),
-         "v_cndmask_b32 %%[y1], v%d, v%d, %s" % (g1["X"] + 1, g1["V0"] + 1, sp(STICKY))] + STICKY_OUT[2:]
+                chains.append(multiply(c, pr[v], pr[src], pr[dst], "%[st]"))
+        seg = schedule(chains)
+        body += seg
+        counts["valu"] += sum(1 for ln in seg if ln.startswith("v_"))
+        counts["nop"] += sum(1 for ln in seg if ln.startswith("s_nop"))
     for i, ln in enumerate(body):
         lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(body) else ""))
-    lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1), [fl] "=&v"(fl)')
+    lines.append('        : "+{v[%d:%d]}"(x), "+{v[%d:%d]}"(y), [st] "+s"(st)' % (g0["X"], g0["X"] + 1, g1["X"], g1["X"] + 1))
     lines.append("        :")
-    clob = ['"v%d"' % r for r in range(BASE, BASE + 4 * N_PAIRS)] + ['"s%d"' % r for r in SGPRS] + ['"scc"', '"vcc"']
+    pinned = {g0["X"], g0["X"] + 1, g1["X"], g1["X"] + 1}
+    clob = ['"v%d"' % r for r in range(BASE, BASE + 4 * N_PAIRS) if r not in pinned] + ['"s%d"' % r for r in SGPRS] + \
+        ['"scc"', '"vcc"']
     lines.append("        : " + ", ".join(clob) + ");")
-    lines += ["    x = mk64(x0, x1);", "    y = mk64(y0, y1);", "    return fl;", "}"]
-    print("%s: %d VALU instructions + %d s_nop for the two values" % (name, counts["valu"], counts["nop"]))
+    lines += ["}"]
+    print("%s: %d VALU instructions + %d s_nop for the two values" % (name, counts["valu"] + 2 * len(zero_inits(g0)), counts["nop"]))
     return lines
 
 
