@@ -109,9 +109,10 @@ def square(c, src=None, dst=None, st=None):
         ("v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (X, s, X, H + 1, sp(S2)), [], [S]),                  # X.lo - h1 - c
         ("v_cndmask_b32 v%d, 0, -1, %s" % (E, sp(S2)), [], []),                                       # c ? 0xffffffff : 0
         ("v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (X + 1, sp(S3), X + 1, E, s), [], [S3]),             # X.hi + c - borrow
+    ] + ([] if os.environ.get("SSA_GEN_NO_STICKY") else [       # (timing probe only: no rare-borrow bookkeeping at all)
         ("s_andn2_b64 %s, %s, %s" % (sp(S3), sp(S3), sp(S2)), [], []),                                # borrow and not c
         ("s_or_b64 %s, %s, %s" % ((sp(STICKY + 2 * c),) * 2 + (sp(S3),) if st is None else (st, st, sp(S3))), [], []),
-    ]
+    ])
 
 
 def reduce_tail(c, dst=None, st=None):
@@ -315,6 +316,11 @@ def _regs_of(text):
     return rd, wr
 
 
+LAT_MAD = int(os.environ.get("SSA_GEN_LAT_MAD", "0"))        # latency model of the list scheduler (0 = none): extra positions a
+LAT_OTHER = int(os.environ.get("SSA_GEN_LAT_OTHER", "0"))    # reader of a multiply-add's / another VALU result should keep
+VALU_GAP = int(os.environ.get("SSA_GEN_VALU_GAP", "3"))     # positions between a VALU write of an SGPR pair and the VALU read
+
+
 def schedule(chains):
     """list scheduling of the chains' instructions together: dependencies from the registers (RAW, WAW, WAR), an
     SGPR pair written by a VALU instruction at position i is readable by a VALU instruction at i + 3 at the earliest
@@ -337,23 +343,29 @@ def schedule(chains):
         for i in preds[j]:
             height[i] = max(height[i], height[j] + 1)
 
+    def lat(t):
+        return LAT_MAD if t.startswith("v_mad_u64") else (LAT_OTHER if t.startswith("v_") else 0)
+
     def place(prio):
         placed_at = {}
         out = []
         last_sgpr_write = {}
+        vready = {}          # VGPR -> first position at which a reader does not wait for it (latency model, LAT_* > 0)
         while len(placed_at) < n:
-            best = None
+            best, best_key = None, None
             for j in range(n):
                 if j in placed_at or any(i not in placed_at for i in preds[j]):
                     continue
                 rd, wr = info[j]
                 # the wait states are a VALU-write -> VALU-read matter (gap 3); the scalar unit's reads of a pair a VALU
                 # instruction wrote are interlocked -- one other instruction is put in between anyway (gap 2)
-                gap = 3 if ins[j].startswith("v_") else 2
+                gap = VALU_GAP if ins[j].startswith("v_") else 2
                 if any(r[0] == "s" and r[1] != 24 and len(out) - last_sgpr_write.get(r, -10) < gap for r in rd):
                     continue
-                if best is None or prio[j] > prio[best]:
-                    best = j
+                wait = max([vready.get(r, 0) - len(out) for r in rd if r[0] == "v"] + [0])
+                key = (-wait, prio[j])
+                if best is None or key > best_key:
+                    best, best_key = j, key
             if best is None:
                 out.append("s_nop 0")
                 continue
@@ -362,18 +374,35 @@ def schedule(chains):
             for r in info[best][1]:
                 if r[0] == "s" and ins[best].startswith("v_"):
                     last_sgpr_write[r] = len(out) - 1
+                if r[0] == "v":
+                    vready[r] = len(out) - 1 + 1 + lat(ins[best])
         return out
 
+    def stalls(seq):
+        """positions a reader sits closer to the producer of one of its VGPR operands than the latency model wants"""
+        ready, tot = {}, 0
+        for pos, t in enumerate(seq):
+            if t.startswith("s_nop"):
+                continue
+            rd, wr = _regs_of(t)
+            tot += max([ready.get(r, 0) - pos for r in rd if r[0] == "v"] + [0])
+            for r in wr:
+                if r[0] == "v":
+                    ready[r] = pos + 1 + lat(t)
+        return tot
+
     # longest remaining path first; the greedy choice is not always the one without padding, so a few hundred
-    # deterministic perturbations of the priorities are tried as well and the schedule with the fewest s_nop kept
+    # deterministic perturbations of the priorities are tried as well and the schedule with the fewest s_nop (then the
+    # fewest modelled stalls) kept
     import random
     rnd = random.Random(len(ins) * 7919 + sum(len(t) for t in ins))
+    cost = lambda seq: (sum(ln.startswith("s_nop") for ln in seq), stalls(seq))
     best_out = place([float(h) for h in height])
     for _ in range(300):
-        if not any(ln.startswith("s_nop") for ln in best_out):
+        if cost(best_out) == (0, 0):
             break
         cand = place([h + rnd.random() * 2.5 for h in height])
-        if sum(ln.startswith("s_nop") for ln in cand) < sum(ln.startswith("s_nop") for ln in best_out):
+        if cost(cand) < cost(best_out):
             best_out = cand
     return best_out
 
