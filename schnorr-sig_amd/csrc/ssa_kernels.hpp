@@ -502,6 +502,10 @@ SSA_FN bool x_on_curve(const fp6 &x) {
 }
 
 constexpr u32 VF_CHECK_TORSION = 1u, VF_SIG_FLAG_BYTE = 8u;
+#ifdef SSA_WAVE_TIMES
+constexpr size_t SSA_WAVE_TIMES_MAX = 1u << 15;
+__device__ unsigned long long g_wave_times[3 * SSA_WAVE_TIMES_MAX];
+#endif
 
 #ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256, 2)
@@ -511,6 +515,9 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
              u8 *__restrict__ status_out, unsigned long long *__restrict__ n_fail) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32 status = ST_OK;
+#ifdef SSA_WAVE_TIMES       // diagnostic build only (tools/wave_times.py): when and where every wave of the kernel ran
+    const unsigned long long wt0 = wall_clock64();
+#endif
     if (i < n) {
         // check order of the reference (src/signature.rs:181-205): the key first (subgroup check, :182),
         // then the signature's x (Fp6::from_bytes(..).unwrap() panics at :186 -> SSA_MALFORMED)
@@ -575,6 +582,17 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
     // aggregate verdict: one ballot + one atomic per wave
     const unsigned long long bad = __ballot(status != ST_OK);
     if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(n_fail, (unsigned long long)__popcll(bad));
+#ifdef SSA_WAVE_TIMES
+    if ((threadIdx.x & 63u) == 0) {
+        const size_t w = i / 64;
+        if (w < SSA_WAVE_TIMES_MAX) {
+            g_wave_times[3 * w] = wt0;
+            g_wave_times[3 * w + 1] = wall_clock64();
+            g_wave_times[3 * w + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                      (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID, HW_ID
+        }
+    }
+#endif
 }
 #endif  // SSA_NO_KERNELS
 
