@@ -50,10 +50,11 @@ SSA_DEV u64 inv_sbox(u64 x) {
     return fp_mul(a, b);
 }
 
-// Two state elements at a time, the whole chain of both in ONE asm block (fp_chain_asm.inc,
+// SSA_FP_CHAINS (three) state elements at a time, the whole chain of all of them in ONE asm block (fp_chain_asm.inc,
 // tools/gen_fp_chain_asm.py): 11 instructions per squaring and 13 per product instead of hipcc's 22-26 + s_nop
-// padding, the two values interleaved by a list scheduler so that the SGPR carries get their wait states; the values are
-// pinned to the blocks' own registers (no moves in or out) and the chain's "copies" are register renamings.
+// padding, the values' instructions interleaved by a list scheduler so that the SGPR carries get their wait states and a
+// dependent instruction sits three or more positions behind its producer; the values are pinned to the blocks' own
+// registers (no moves in or out) and the chain's "copies" are register renamings.
 // The blocks do not repair the one rare event of their reduction (a borrow with probability ~2^-32 per squaring, see
 // the generator): they OR the lanes that met it into a wave-wide mask.  The caller tests the mask on the scalar unit
 // (one compare and one branch per block, no vector instruction) and recomputes the S-boxes of a flagged lane -- about one
@@ -73,41 +74,52 @@ SSA_DEV bool lane_bit(u64 mask) {
     const u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     return ((mask >> lane) & 1ull) != 0;
 }
+#else
+#define SSA_FP_CHAINS 3
 #endif
-// x <- x^(1/7), y <- y^(1/7) for the state elements at px, py (read here, written back by the caller)
-SSA_DEV void inv_sbox2(const u64 *px, const u64 *py, u64 &x, u64 &y) {
-    x = *px;
-    y = *py;
-#ifdef SSA_FP_CHAIN_ASM
+static_assert(12 % SSA_FP_CHAINS == 0 && (SSA_FP_CHAINS == 2 || SSA_FP_CHAINS == 3), "S-box blocks of 2 or 3 state elements");
+
+// One S-box block IN PLACE on SSA_FP_CHAINS state elements (p[0], p[1], ...: the inputs are read here and, for a lane the
+// asm block flags, read again).  INV: x^(1/7), else x^7.  Returns the asm block's mask (0 on the compiled path).
+template <bool INV>
+SSA_DEV u64 sbox_block(u64 *const (&p)[SSA_FP_CHAINS]) {
     u64 st = 0;
-    inv_sbox2_asm(x, y, st);
+#ifdef SSA_FP_CHAIN_ASM
+    u64 v[SSA_FP_CHAINS];
+#pragma unroll
+    for (int k = 0; k < SSA_FP_CHAINS; k++) v[k] = *p[k];
+#if SSA_FP_CHAINS == 3
+    if (INV) inv_sbox_n_asm(v[0], v[1], v[2], st);
+    else sbox_n_asm(v[0], v[1], v[2], st);
+#else
+    if (INV) inv_sbox_n_asm(v[0], v[1], st);
+    else sbox_n_asm(v[0], v[1], st);
+#endif
     if (st != 0) {                 // wave-uniform: some lane of the wave met the rare borrow
         if (lane_bit(st)) {
-            x = inv_sbox(*px);
-            y = inv_sbox(*py);
+#pragma unroll
+            for (int k = 0; k < SSA_FP_CHAINS; k++) v[k] = INV ? inv_sbox(*p[k]) : sbox(*p[k]);
         }
     }
+#pragma unroll
+    for (int k = 0; k < SSA_FP_CHAINS; k++) *p[k] = v[k];
 #else
-    x = inv_sbox(x);
-    y = inv_sbox(y);
+#pragma unroll
+    for (int k = 0; k < SSA_FP_CHAINS; k++) *p[k] = INV ? inv_sbox(*p[k]) : sbox(*p[k]);
 #endif
+    return st;
 }
-SSA_DEV void sbox2(const u64 *px, const u64 *py, u64 &x, u64 &y) {
-    x = *px;
-    y = *py;
-#ifdef SSA_FP_CHAIN_ASM
-    u64 st = 0;
-    sbox2_asm(x, y, st);
-    if (st != 0) {
-        if (lane_bit(st)) {
-            x = sbox(*px);
-            y = sbox(*py);
-        }
+// the S-box layer of the 12-element state at `st` (element i at st[i * RS_STRIDE]): blocks (i, i + n, i + 2n), n = 12 / chains
+template <bool INV>
+SSA_DEV void sbox_layer(u64 *state, int stride) {
+    constexpr int NB = 12 / SSA_FP_CHAINS;
+#pragma unroll 1
+    for (int i = 0; i < NB; i++) {
+        u64 *p[SSA_FP_CHAINS];
+#pragma unroll
+        for (int k = 0; k < SSA_FP_CHAINS; k++) p[k] = state + (i + k * NB) * stride;
+        sbox_block<INV>(p);
     }
-#else
-    x = sbox(x);
-    y = sbox(y);
-#endif
 }
 
 // The 12-felt sponge state of a lane lives in LDS ("LDS-staged"): element i of lane t is
@@ -183,23 +195,11 @@ SSA_DEV void rescue_permutation(u64 *A, u64 *B, const DevParams *__restrict__ pr
     const bool tiny = (prm->flags & PRM_FLAG_TINY_MDS) != 0;
 #pragma unroll 1
     for (u32 r = 0; r < nr; r++) {
-#pragma unroll 1
-        for (int i = 0; i < 6; i++) {  // two independent chains per iteration
-            u64 x, y;
-            sbox2(A + i * RS_STRIDE, A + (i + 6) * RS_STRIDE, x, y);
-            A[i * RS_STRIDE] = x;
-            A[(i + 6) * RS_STRIDE] = y;
-        }
+        sbox_layer<false>(A, RS_STRIDE);
         if (tiny) mds_ark_tiny(A, B, prm->mds, prm->ark1 + 12 * r);
         else if (small) mds_ark<true>(A, B, prm->mds, prm->ark1 + 12 * r);
         else mds_ark<false>(A, B, prm->mds, prm->ark1 + 12 * r);
-#pragma unroll 1
-        for (int i = 0; i < 6; i++) {
-            u64 x, y;
-            inv_sbox2(B + i * RS_STRIDE, B + (i + 6) * RS_STRIDE, x, y);
-            B[i * RS_STRIDE] = x;
-            B[(i + 6) * RS_STRIDE] = y;
-        }
+        sbox_layer<true>(B, RS_STRIDE);
         if (tiny) mds_ark_tiny(B, A, prm->mds, prm->ark2 + 12 * r);
         else if (small) mds_ark<true>(B, A, prm->mds, prm->ark2 + 12 * r);
         else mds_ark<false>(B, A, prm->mds, prm->ark2 + 12 * r);

@@ -166,7 +166,7 @@ ssa_k_hash(const DevParams *__restrict__ prm, const u8 *__restrict__ sigs,
 #endif  // SSA_NO_KERNELS
 
 #ifndef SSA_NO_KERNELS
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 ssa_k_rescue(const DevParams *__restrict__ prm, const u64 *__restrict__ felts, u32 per_row,
              size_t n, u64 *__restrict__ out) {
     __shared__ u64 lds[RS_LDS_U64];
@@ -1169,26 +1169,26 @@ __global__ void ssa_k_debug(int op, const u64 *__restrict__ a, const u64 *__rest
         return;
     }
     if (op == 18) {   // the Rescue S-boxes on RAW loose values: a = (x, y) -> x^7, y^7, x^(1/7), y^(1/7), asm flags
-        // po[0..3]: the product's wrappers (asm block, then the compiled exact chain for a lane the block flagged);
-        // po[4], po[5]: this lane's bit of the mask sbox2_asm / inv_sbox2_asm collect
-        u64 x, y;
-        sbox2(pa, pa + 1, x, y);
-        po[0] = fp_canon(x);
-        po[1] = fp_canon(y);
-        inv_sbox2(pa, pa + 1, x, y);
-        po[2] = fp_canon(x);
-        po[3] = fp_canon(y);
-        po[4] = po[5] = 0;
+        // the product's block wrapper (asm block, then the compiled exact chain for a lane the block flagged) on the values
+        // (x, y, x); po[4], po[5]: this lane's bit of the mask the forward / inverse asm block returned
+        u64 t[3] = {pa[0], pa[1], pa[0]};
+        u64 *p[SSA_FP_CHAINS];
+#pragma unroll
+        for (int k = 0; k < SSA_FP_CHAINS; k++) p[k] = t + k;
+        u64 st = sbox_block<false>(p);
+        po[0] = fp_canon(t[0]);
+        po[1] = fp_canon(t[1]);
+        po[4] = 0;
 #ifdef SSA_FP_CHAIN_ASM
-        u64 st = 0;
-        x = pa[0];
-        y = pa[1];
-        sbox2_asm(x, y, st);
         po[4] = lane_bit(st) ? 1u : 0u;
-        st = 0;
-        x = pa[0];
-        y = pa[1];
-        inv_sbox2_asm(x, y, st);
+#endif
+        t[0] = t[2] = pa[0];
+        t[1] = pa[1];
+        st = sbox_block<true>(p);
+        po[2] = fp_canon(t[0]);
+        po[3] = fp_canon(t[1]);
+        po[5] = 0;
+#ifdef SSA_FP_CHAIN_ASM
         po[5] = lane_bit(st) ? 1u : 0u;
 #endif
         return;

@@ -19,10 +19,11 @@ uint64_t ha_fp_inv(uint64_t a) { return fp_canon(fp_inv(a)); }
 uint64_t ha_fp_mul_small(uint64_t a, uint32_t k) { return fp_canon(fp_mul_small(a, k)); }
 uint64_t ha_inv_sbox(uint64_t a) { return fp_canon(inv_sbox(a)); }
 uint64_t ha_inv_sbox2(uint64_t a, uint64_t b, uint64_t *ob) {
-    uint64_t x, y;
-    inv_sbox2(&a, &b, x, y);
-    *ob = fp_canon(y);
-    return fp_canon(x);
+    uint64_t t[3] = {a, b, a};
+    uint64_t *p[SSA_FP_CHAINS] = {t, t + 1, t + 2};
+    sbox_block<true>(p);
+    *ob = fp_canon(t[1]);
+    return fp_canon(t[0]);
 }
 static fp6 ld(const uint64_t *p) {
     fp6 r;

@@ -21,65 +21,69 @@ import asm_interp as ai
 F6_INC = os.path.join(os.path.dirname(INC), "fp6_asm.inc")
 
 
-def run(txt_blocks, fn, x, y):
-    """-> (x', y', flag): flag != 0 means a reduction met its rare borrow and x', y' are to be recomputed.
-    fp_sqr2_n_asm takes its values as named operands and returns a per-lane flag; the two S-box programs have their values
-    PINNED to the chains' value registers and OR the flagged lanes into the mask operand %[st]."""
-    lines, outs, _ = txt_blocks[fn]
-    if fn == "fp_sqr2_n_asm":
-        env = {"%[x0]": x & M32, "%[x1]": x >> 32, "%[y0]": y & M32, "%[y1]": y >> 32, "%[n]": 5}
-        lane = ai.Lane(env, dummy_pairs=("s[24:25]",))
-        e = lane.run(lines)
-        return e["%[x0]"] | (e["%[x1]"] << 32), e["%[y0]"] | (e["%[y1]"] << 32), e["%[fl]"]
+def run(txt_blocks, fn, vals):
+    """-> ([x', ...], flag): the values of the block's chains (PINNED to the chains' value registers) after the program, and
+    this lane's bit of the mask operand %[st] -- non-zero means a reduction met its rare borrow and the values are to be
+    recomputed by the caller"""
     import gen_fp_chain_asm as g
-    rx, ry = g.regs(0)["X"], g.regs(1)["X"]
-    lane = ai.Lane({}, dummy_pairs=("s[24:25]",))
-    lane.v[rx], lane.v[rx + 1], lane.v[ry], lane.v[ry + 1] = x & M32, x >> 32, y & M32, y >> 32
+    lines, outs, _ = txt_blocks[fn]
+    assert len(vals) == g.NCH
+    lane = ai.Lane({}, dummy_pairs=(g.DUMMY,))
+    for c, x in enumerate(vals):
+        r = g.regs(c)["X"]
+        lane.v[r], lane.v[r + 1] = x & M32, x >> 32
     lane.run(lines)
-    return lane.v[rx] | (lane.v[rx + 1] << 32), lane.v[ry] | (lane.v[ry + 1] << 32), lane.s.get("%[st]", 0)
+    out = [lane.v[g.regs(c)["X"]] | (lane.v[g.regs(c)["X"] + 1] << 32) for c in range(g.NCH)]
+    return out, lane.s.get("%[st]", 0)
 
 
 def test_generated_sbox_asm_on_the_cpu():
+    import gen_fp_chain_asm as g
     txt = ai.extract_blocks(INC)
-    assert set(txt) == {"fp_sqr2_n_asm", "inv_sbox2_asm", "sbox2_asm"}
+    assert set(txt) == {"inv_sbox_n_asm", "sbox_n_asm"}
     rnd = random.Random(5)
     e_inv = 10540996611094048183          # 7^-1 mod (p - 1)
     vals = [0, 1, P - 1, P, P + 1, 2**64 - 1, 2**32, 2**32 - 1, 2**63, 2**64 - 2**32] + [rnd.randrange(2**64) for _ in range(30)]
     flagged = 0
     for i, a in enumerate(vals):
-        b = vals[(i * 7 + 3) % len(vals)]
-        for fn, want in (("inv_sbox2_asm", lambda v: pow(v, e_inv, P)), ("sbox2_asm", lambda v: pow(v, 7, P)),
-                         ("fp_sqr2_n_asm", lambda v: pow(v, 32, P))):      # n = 5 in the interpreter
-            rx, ry, fl = run(txt, fn, a, b)
+        ins = [vals[(i * (7 + 4 * c) + 3 * c) % len(vals)] for c in range(g.NCH)]
+        for fn, want in (("inv_sbox_n_asm", lambda v: pow(v, e_inv, P)), ("sbox_n_asm", lambda v: pow(v, 7, P))):
+            got, fl = run(txt, fn, ins)
             flagged += bool(fl)
             # a flagged lane is recomputed by the caller; an unflagged one must be right
-            assert fl or (rx % P == want(a) and ry % P == want(b)), (fn, hex(a), hex(b))
-    assert flagged <= 6          # only the hand-picked edge values can get there (2^32 * 2^32 = 2^64, ...)
+            assert fl or [v % P for v in got] == [want(v) for v in ins], (fn, [hex(v) for v in ins])
+    assert flagged <= 8          # only the hand-picked edge values can get there (2^32 * 2^32 = 2^64, ...)
 
 
 def test_sbox_programs_execute_no_copy_and_no_loop():
     """round 4: the chains' `cp` steps are register renamings and the squaring runs are straight code; the statement has no
     move in or out (values pinned), so its VALU count is the arithmetic's: 63 squarings x 11 + 9 products x 13 per value"""
+    import gen_fp_chain_asm as g
     txt = ai.extract_blocks(INC)
-    for fn, n_sq, n_mul in (("inv_sbox2_asm", 63, 9), ("sbox2_asm", 2, 2)):
+    for fn, n_sq, n_mul in (("inv_sbox_n_asm", 63, 9), ("sbox_n_asm", 2, 2)):
         lines = txt[fn][0]
         valu = [ln for ln in lines if ln.startswith("v_")]
-        assert len(valu) == 2 * (11 * n_sq + 13 * n_mul) + 2, (fn, len(valu))       # + the two zero high words
+        assert len(valu) == g.NCH * (11 * n_sq + 13 * n_mul + 1), (fn, len(valu))       # + one zero high word per chain
         assert not any(ln.startswith(("s_cbranch", "s_branch")) or ln.endswith(":") for ln in lines), fn
         movs = [ln for ln in valu if ln.startswith("v_mov_b32")]
-        assert len(movs) == 2 + 2 * 4 * n_mul, (fn, len(movs))                      # only the product head's four word moves
+        assert len(movs) == g.NCH * (1 + 4 * n_mul), (fn, len(movs))                    # only the product head's four word moves
+        assert not any(ln.startswith("s_nop") for ln in lines), fn
 
 
 def test_sbox_asm_reports_the_rare_borrow():
     """a = k 2^48: a^2 = k^2 2^96, so lo = 0, hi.lo = 0, hi.hi = k^2 -- the reduction X - h1 borrows with no carry to
-    cancel it.  The block must flag such a lane (in either chain) instead of passing a wrong value on silently: the S-box
-    programs OR it into their mask operand (the caller re-hashes the lane), fp_sqr2_n_asm returns it."""
+    cancel it.  The block must flag such a lane (in whichever chain) instead of passing a wrong value on silently: the S-box
+    programs OR it into their mask operand (the caller recomputes the lane's values from its inputs)."""
+    import gen_fp_chain_asm as g
     txt = ai.extract_blocks(INC)
     for k in (1, 3, 0xffff):
         a = k << 48
-        for fn in ("inv_sbox2_asm", "sbox2_asm", "fp_sqr2_n_asm"):
-            assert run(txt, fn, a, 5)[2] == 1 and run(txt, fn, 5, a)[2] == 1, (fn, k)
-            assert run(txt, fn, 5, 7)[2] == 0
+        for fn in ("inv_sbox_n_asm", "sbox_n_asm"):
+            for c in range(g.NCH):
+                ins = [5 + j for j in range(g.NCH)]
+                ins[c] = a
+                assert run(txt, fn, ins)[1] == 1, (fn, k, c)
+            assert run(txt, fn, [5 + j for j in range(g.NCH)])[1] == 0
 
 
 def test_reduction_tail_is_exact_or_flagged():
@@ -89,7 +93,7 @@ def test_reduction_tail_is_exact_or_flagged():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import gen_fp_chain_asm as g
     regs = g.regs(0)
-    lines = g.schedule([g.reduce_tail(0)])
+    lines = g.schedule([g.reduce_tail(0, None, "%[st]")])
     rnd = random.Random(77)
     EPS = 2**32 - 1
     h_vals = [0, 1, 2, EPS, EPS - 1, 2**31] + [rnd.randrange(2**32) for _ in range(6)]
@@ -101,17 +105,17 @@ def test_reduction_tail_is_exact_or_flagged():
                    (base + h1) % 2**64, (base + h1 - 1) % 2**64, (base + h1 + 1) % 2**64, 2**32 - 1, 2**32}
             los |= {rnd.randrange(2**64) for _ in range(4)}
             for lo in los:
-                lane = ai.Lane({}, dummy_pairs=("s[24:25]",))
+                lane = ai.Lane({}, dummy_pairs=(g.DUMMY,))
                 lane.v[regs["T"]], lane.v[regs["T"] + 1] = lo & M32, lo >> 32
                 lane.v[regs["H"]], lane.v[regs["H"] + 1] = h0, h1
-                lane.s[g.STICKY] = 0
+                lane.s["%[st]"] = 0
                 lane.run(lines)
                 x = lane.v[regs["X"]] | (lane.v[regs["X"] + 1] << 32)
                 full = lo + EPS * h0
                 carry, X = full >> 64, full & M64
                 assert carry <= 1
                 negative = carry == 0 and X < h1
-                assert lane.s[g.STICKY] == int(negative), (hex(lo), hex(h0), hex(h1))
+                assert lane.s["%[st]"] == int(negative), (hex(lo), hex(h0), hex(h1))
                 n_flag += negative
                 n_carry += carry
                 if not negative:

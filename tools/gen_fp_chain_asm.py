@@ -31,21 +31,27 @@ reports the lanes that hit it, and the C++ wrapper recomputes those lanes' S-box
 """
 import os
 
-# fixed registers per chain (c = 0, 1); all above the compiler's own allocation for ssa_k_hash, all below v128
-BASE = 72
-N_PAIRS = 14      # X T A U H R M E C + saved values V0..V4
+# Chains per block (round 4: THREE).  The squaring is a dependent sequence of eleven instructions; with two chains a reader
+# sits two or three positions behind its producer, and even four waves per SIMD do not hide that: a pure squaring stream
+# costs 4.73 cycles per instruction with two chains, 4.35 with three, 4.33 with four, 4.39 with six (tools/isa_probe,
+# probes sq_chains_N, four waves per SIMD; at two waves three chains cost 4.71).  Three chains of 13 register pairs are 78
+# VGPRs (v50..v127): the kernel keeps its 128 registers = four waves per SIMD.  (Round 1 tried six chains and lost a wave
+# of occupancy; round 3 costed three as "no instruction disappears" -- true, and beside the point.)  SSA_GEN_CHAINS=2 for A/B.
+NCH = int(os.environ.get("SSA_GEN_CHAINS", "3"))
+N_PAIRS = 13      # T A U H M E C + the six value pairs X V0..V4
+BASE = 128 - 2 * NCH * N_PAIRS      # all above the compiler's own allocation for ssa_k_hash, all below v128
 
 
 def regs(c):
-    o = BASE + 2 * c
-
+    """chain c's register pairs (interleaved with the other chains': pair k of chain c is BASE + 2 c + 2 NCH k) and its three
+    carry pairs S, S2, S3 (s32 / s33 are the stack and frame pointers)"""
     def pair(k):
-        return o + 4 * k
+        return BASE + 2 * c + 2 * NCH * k
 
-    g = {"X": pair(0), "T": pair(1), "A": pair(2), "U": pair(3), "H": pair(4), "R": pair(5), "M": pair(6), "E": pair(7),
-         "C": pair(8), "S": 20 + 2 * c}
+    g = {"X": pair(0), "T": pair(1), "A": pair(2), "U": pair(3), "H": pair(4), "M": pair(5), "E": pair(6), "C": pair(7),
+         "S": 20 + 2 * c, "S2": 26 + 2 * c, "S3": 36 + 2 * c}
     for k in range(5):
-        g["V%d" % k] = pair(9 + k)
+        g["V%d" % k] = pair(8 + k)
     return g
 
 
@@ -57,14 +63,7 @@ def regs(c):
 MOVES_HEAD = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "carries"       # "moves" (default), "moves10", "carries"
 SQ_MERGE_FAST = os.environ.get("SSA_GEN_SQ_MERGE", "") == "fast"
 MUL_HEAD_ADD1 = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "moves10"     # round 4 default; "moves10" = round 3's head
-# Squarings per loop iteration inside the S-box programs; 0 (default since round 4) = no loops at all: the 58 squarings of the
-# five `square n times` runs are emitted straight (1652 VALU instructions, 13 KB: the instruction cache holds them).  The
-# three scalar instructions and the taken branch per iteration were not free even at four waves per SIMD: ssa_k_hash
-# 8.35 / 8.36 / 8.25 ms with loops against 8.20 / 8.14 / 8.16 ms without, same box, alternating (unrolling by 2 or 4: no
-# gain) -- profiles/r04/hash_ab.txt (e).
-SQ_UNROLL = int(os.environ.get("SSA_GEN_SQ_UNROLL", "0"))
-DUMMY = "s[24:25]"     # carry-outs nobody reads
-STICKY = 40            # s[40:41] / s[42:43]: lanes of chain 0 / 1 whose reduction met the rare borrow (see the docstring)
+DUMMY = "s[42:43]"     # carry-outs nobody reads
 SGPRS = list(range(20, 32)) + list(range(36, 44))
 
 
@@ -81,11 +80,10 @@ def square(c, src=None, dst=None, st=None):
     the value is read from and written to (default: in place in X); st: the asm operand that collects the rare-borrow
     lanes (default: the chain's own sticky pair)"""
     g = regs(c)
-    X, T, A, U, H, R, M, E, C, S = (g[k] for k in "XTAUHRMECS")
+    X, T, A, U, H, M, E, C, S, S2, S3 = (g[k] for k in ("X", "T", "A", "U", "H", "M", "E", "C", "S", "S2", "S3"))
     XS = X if src is None else src          # the three products read the source pair ...
     X = X if dst is None else dst           # ... the reduction writes the destination pair
-    S2 = S + 8            # second carry pair of the chain: s[28:29] / s[30:31]
-    S3 = S + 16           # scratch mask: s[36:37] / s[38:39] (s32 / s33 are the stack and frame pointers)
+    assert st is not None                   # the asm operand that collects the lanes of the rare borrow
     s = sp(S)
     return [
         ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, XS, XS), [], []),
@@ -111,7 +109,7 @@ def square(c, src=None, dst=None, st=None):
         ("v_subb_co_u32 v%d, %s, v%d, v%d, %s" % (X + 1, sp(S3), X + 1, E, s), [], [S3]),             # X.hi + c - borrow
     ] + ([] if os.environ.get("SSA_GEN_NO_STICKY") else [       # (timing probe only: no rare-borrow bookkeeping at all)
         ("s_andn2_b64 %s, %s, %s" % (sp(S3), sp(S3), sp(S2)), [], []),                                # borrow and not c
-        ("s_or_b64 %s, %s, %s" % ((sp(STICKY + 2 * c),) * 2 + (sp(S3),) if st is None else (st, st, sp(S3))), [], []),
+        ("s_or_b64 %s, %s, %s" % (st, st, sp(S3)), [], []),
     ])
 
 
@@ -129,7 +127,7 @@ def multiply(c, saved, src=None, dst=None, st=None):
     X, T, A, U, H, C, E, V, S = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved] if isinstance(saved, str) else saved, g["S"]
     if src is not None:
         X = src                 # the head reads the source pair; the reduction writes dst (reduce_tail)
-    S2, S3 = S + 8, S + 16
+    S2, S3 = g["S2"], g["S3"]
     if MOVES_HEAD and not MUL_HEAD_ADD1:        # round 3's head: 10 instructions
         return [
             ("v_mad_u64_u32 %s, %s, v%d, v%d, 0" % (vp(T), DUMMY, X, V), [], []),
@@ -199,12 +197,6 @@ INV_SBOX = [("cp", "V0", "X"), ("sq", 1), ("cp", "V1", "X"), ("sq", 1), ("cp", "
 SBOX = [("cp", "V0", "X"), ("sq", 1), ("cp", "V1", "X"), ("sq", 1), ("mul", "V1"), ("mul", "V0")]   # x^7 = x^4 x^2 x
 
 
-# the sticky "rare borrow" masks of the two chains: cleared on entry; on exit their OR becomes the per-lane flag
-STICKY_INIT = ["s_mov_b64 %s, 0" % sp(STICKY), "s_mov_b64 %s, 0" % sp(STICKY + 2)]
-STICKY_OUT = ["s_or_b64 %s, %s, %s" % (sp(STICKY), sp(STICKY), sp(STICKY + 2)), "s_nop 2",
-              "v_cndmask_b32 %%[fl], 0, 1, %s" % sp(STICKY)]
-
-
 VALUE_PAIRS = ["X", "V0", "V1", "V2", "V3", "V4"]     # the six pairs a chain's values live in (the roles move: see rename)
 
 
@@ -256,20 +248,23 @@ def rename(prog):
     return out
 
 
+ARGS = ["x", "y", "z", "w"][:NCH]
+
+
 def emit_program(name, prog, doc):
-    g0, g1 = regs(0), regs(1)
+    gs = [regs(c) for c in range(NCH)]
     lines = ["// %s" % doc,
-             "// x and y are pinned to the blocks' own value registers (no moves in or out; the compiler loads the state",
-             "// straight into them); st collects the lanes (bit per lane) where a reduction met its rare borrow: their x and y are",
-             "// then WRONG and the caller recomputes the whole hash of such a lane with the compiled exact code (rescue.hpp)",
-             "SSA_DEV void %s(u64 &x, u64 &y, u64 &st) {" % name, "    asm volatile("]
+             "// The values are pinned to the blocks' own value registers (no moves in or out; the compiler loads the state",
+             "// straight into them); st collects the lanes (bit per lane) where a reduction met its rare borrow: their values are",
+             "// then WRONG and the caller recomputes them from its inputs with the compiled exact code (rescue.hpp)",
+             "SSA_DEV void %s(%s, u64 &st) {" % (name, ", ".join("u64 &" + a for a in ARGS)), "    asm volatile("]
     body = []
-    for g in (g0, g1):
+    for g in gs:
         body += zero_inits(g)
-    counts = {"valu": 0, "nop": 0}
+    counts = {"valu": len(body), "nop": 0}
     for kind, v, src, dst in rename(prog):
         chains = []
-        for c, g in ((0, g0), (1, g1)):
+        for c, g in enumerate(gs):
             pr = [g[nm] for nm in VALUE_PAIRS]
             if kind == "sq":
                 chains.append(square(c, pr[src], pr[dst], "%[st]"))
@@ -281,14 +276,14 @@ def emit_program(name, prog, doc):
         counts["nop"] += sum(1 for ln in seg if ln.startswith("s_nop"))
     for i, ln in enumerate(body):
         lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(body) else ""))
-    lines.append('        : "+{v[%d:%d]}"(x), "+{v[%d:%d]}"(y), [st] "+s"(st)' % (g0["X"], g0["X"] + 1, g1["X"], g1["X"] + 1))
+    lines.append("        : " + ", ".join('"+{v[%d:%d]}"(%s)' % (g["X"], g["X"] + 1, a) for g, a in zip(gs, ARGS)) + ', [st] "+s"(st)')
     lines.append("        :")
-    pinned = {g0["X"], g0["X"] + 1, g1["X"], g1["X"] + 1}
-    clob = ['"v%d"' % r for r in range(BASE, BASE + 4 * N_PAIRS) if r not in pinned] + ['"s%d"' % r for r in SGPRS] + \
+    pinned = {r for g in gs for r in (g["X"], g["X"] + 1)}
+    clob = ['"v%d"' % r for r in range(BASE, BASE + 2 * NCH * N_PAIRS) if r not in pinned] + ['"s%d"' % r for r in SGPRS] + \
         ['"scc"', '"vcc"']
     lines.append("        : " + ", ".join(clob) + ");")
     lines += ["}"]
-    print("%s: %d VALU instructions + %d s_nop for the two values" % (name, counts["valu"] + 2 * len(zero_inits(g0)), counts["nop"]))
+    print("%s: %d VALU instructions + %d s_nop for the %d values" % (name, counts["valu"], counts["nop"], NCH))
     return lines
 
 
@@ -413,48 +408,12 @@ OUT_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 
 def generate():
     """the text of fp_chain_asm.inc (the freshness test compares it with the committed file without writing anything)"""
-    body = schedule([square(0), square(1)])
-    n_valu = sum(1 for ln in body if ln.startswith("v_"))
-    n_nop = sum(1 for ln in body if ln.startswith("s_nop"))
-    g0, g1 = regs(0), regs(1)
-    lines = []
-    lines.append("// generated by tools/gen_fp_chain_asm.py -- do not edit (see that file for the design notes)")
-    lines.append("// x <- x^(2^n), y <- y^(2^n) (mod p, loose in / loose out), n >= 1: %d VALU instructions and %d s_nop per"
-                 % (n_valu, n_nop))
-    lines.append("// pair of squarings.  Returns non-zero in the lanes where a reduction met its rare borrow (results invalid there).")
-    lines.append("SSA_DEV u32 fp_sqr2_n_asm(u64 &x, u64 &y, int n) {")
-    lines.append("    u32 x0 = lo32(x), x1 = hi32(x), y0 = lo32(y), y1 = hi32(y), fl;")
-    lines.append("    asm volatile(")
-    pre = STICKY_INIT + ["v_mov_b32 v%d, %%[x0]" % g0["X"], "v_mov_b32 v%d, %%[x1]" % (g0["X"] + 1),
-                         "v_mov_b32 v%d, %%[y0]" % g1["X"], "v_mov_b32 v%d, %%[y1]" % (g1["X"] + 1)]
-    for g in (g0, g1):
-        pre += zero_inits(g)
-    pre += ["s_mov_b32 s26, %[n]"]
-    for ln in pre:
-        lines.append('        "%s\\n\\t"' % ln)
-    lines.append('        "L_fp_sqr2_%=:\\n\\t"')
-    for ln in body:
-        lines.append('        "%s\\n\\t"' % ln)
-    for ln in ["s_sub_u32 s26, s26, 1", "s_cmp_lg_u32 s26, 0", "s_cbranch_scc1 L_fp_sqr2_%="]:
-        lines.append('        "%s\\n\\t"' % ln)
-    post = ["v_mov_b32 %%[x0], v%d" % g0["X"], "v_mov_b32 %%[x1], v%d" % (g0["X"] + 1),
-            "v_mov_b32 %%[y0], v%d" % g1["X"], "v_mov_b32 %%[y1], v%d" % (g1["X"] + 1)] + STICKY_OUT
-    for i, ln in enumerate(post):
-        lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(post) else ""))
-    lines.append('        : [x0] "+v"(x0), [x1] "+v"(x1), [y0] "+v"(y0), [y1] "+v"(y1), [fl] "=&v"(fl)')
-    lines.append('        : [n] "s"(n)')
-    used = sorted(set(range(BASE, BASE + 4 * 9)))
-    progs = emit_program("inv_sbox2_asm", INV_SBOX, "x <- x^(1/7), y <- y^(1/7): the whole 63-squaring / 9-product chain of "
-                         "both values in one block") + [""] + \
-        emit_program("sbox2_asm", SBOX, "x <- x^7, y <- y^7")
-    clob = ['"v%d"' % r for r in used] + ['"s%d"' % r for r in SGPRS] + ['"scc"', '"vcc"']
-    lines.append("        : " + ", ".join(clob) + ");")
-    lines.append("    x = mk64(x0, x1);")
-    lines.append("    y = mk64(y0, y1);")
-    lines.append("    return fl;")
-    lines.append("}")
-    print("%d VALU + %d s_nop per pair of squarings" % (n_valu, n_nop))
-    return "\n".join(lines + [""] + progs) + "\n"
+    lines = ["// generated by tools/gen_fp_chain_asm.py -- do not edit (see that file for the design notes)",
+             "#define SSA_FP_CHAINS %d      // state elements per S-box block" % NCH, ""]
+    progs = emit_program("inv_sbox_n_asm", INV_SBOX, "x <- x^(1/7) for %d values: the whole 63-squaring / 9-product chain of "
+                         "all of them in one block, interleaved" % NCH) + [""] + \
+        emit_program("sbox_n_asm", SBOX, "x <- x^7 for %d values" % NCH)
+    return "\n".join(lines + progs) + "\n"
 
 
 def main():

@@ -222,6 +222,37 @@ probe("coef_valu", _coef_valu(), n_instr=59)
 probe("coef_salu_c1", _coef_salu(), n_instr=59)        # reported per instruction of the SHIPPED form: directly comparable
 
 
+# ---- round 4 (second session): the Rescue squaring (tools/gen_fp_chain_asm.py) on TWO against THREE interleaved chains:
+# does a third independent chain buy issue slots (the S-box blocks are sensitive to the distance between dependent
+# instructions: profiles/r04/hash_ab.txt (g))?  Cycles per instruction; 11 instructions per squaring and chain.
+def _sq_chains(n):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import gen_fp_chain_asm as g
+
+    def regs_n(c):
+        pair = lambda k: 40 + 2 * c + 2 * n * k
+        d = {"X": pair(0), "T": pair(1), "A": pair(2), "U": pair(3), "H": pair(4), "R": pair(5), "M": pair(6), "E": pair(7),
+             "C": pair(8), "S": 38 + 2 * c}
+        return d
+    old = (g.regs, g.DUMMY)
+    g.regs, g.DUMMY = regs_n, "s[60:61]"
+    try:
+        chains = [g.square(c, None, None, "s[62:63]") for c in range(n)]
+        seq = g.schedule(chains)
+    finally:
+        g.regs, g.DUMMY = old
+    assert not any(ln.startswith("s_nop") for ln in seq), seq
+    return seq
+
+
+for _n in (1, 2, 3, 4, 5, 6):
+    try:
+        probe("sq_chains_%d" % _n, _sq_chains(_n), n_instr=11 * _n, setup="chains")
+    except AssertionError:
+        pass
+
+
 def body(pattern):
     lines = []
     for i in range(R):
@@ -237,7 +268,7 @@ def body(pattern):
 def main():
     out = ["// generated by tools/isa_probe/gen.py -- do not edit", "#include <hip/hip_runtime.h>", "#include <cstdio>",
            "#include <cstring>", "#include <vector>", ""]
-    clob = ", ".join('"v%d"' % r for r in range(10, 40)) + ", " + ", ".join('"s%d"' % r for r in range(36, 64)) + \
+    clob = ", ".join('"v%d"' % r for r in range(10, 128)) + ", " + ", ".join('"s%d"' % r for r in range(36, 64)) + \
         ', "vcc", "scc", "memory"'
     for name, pattern, n_instr, setup in PROBES:
         lines = body(pattern)
@@ -248,6 +279,9 @@ def main():
         pre = ["v_mov_b32 v%d, %%1" % r for r in range(10, 40)]
         pre += ["v_lshlrev_b32 v18, 4, %1", "s_mov_b64 vcc, exec", "s_mov_b64 s[60:61], exec", "s_mov_b64 s[62:63], 0", "s_mov_b32 s36, %2"]
         pre += ["s_mov_b64 s[%d:%d], 0" % (s, s + 1) for s in range(40, 60, 2)]
+        if setup == "chains":       # the chains' value pairs = the lane index (any value), every other register 0
+            pre += ["v_mov_b32 v%d, 0" % r for r in range(40, 128)]
+            pre += ["v_mov_b32 v%d, %%1" % r for r in range(40, 46)]
         for ln in pre:
             out.append('        "%s\\n\\t"' % ln)
         out.append('        "L_%s_%%=:\\n\\t"' % name)
