@@ -76,7 +76,11 @@ SSA_DEV jac jac_dbl(const jac &p) {
 // forms of 2a / 7a).  -DSSA_NO_JAC_ASM and the host build: the compiled doubling in a loop.
 #if defined(SSA_F6_ASM) && !defined(SSA_NO_JAC_ASM)
 #define SSA_JAC_ASM 1
+#ifdef SSA_JAC_ASM_INC           // an alternative generated file (A/B builds: tools/build_variants.sh)
+#include SSA_JAC_ASM_INC
+#else
 #include "jac_asm.inc"
+#endif
 #endif
 SSA_DEV jac jac_dbl_n(jac p, u32 n) {
     if (n == 0) return p;     // the generated loop counts down to zero: n == 0 would wrap to 2^32 iterations

@@ -149,6 +149,27 @@ class Lane:
                 scc = self.s[kd] != 0
             elif op == "s_branch":
                 pc = labels[a[0]]
+            # ---- the fair-turn sequence of the ladder statements (tools/gen_jac_asm.py): a time slice of the wall clock XOR
+            # the wave's slot picks the priority; one lane has no sibling to share a SIMD with, so the clock (`self.clock`,
+            # settable by a test) and the slot (`self.slot`) are plain values and s_setprio is recorded
+            elif op == "s_memrealtime":
+                k = self._key(a[0])
+                t = getattr(self, "clock", 0)
+                self.salu32[k], self.salu32[k + 1] = t & M32, (t >> 32) & M32
+            elif op == "s_waitcnt":
+                pass
+            elif op == "s_lshr_b32":
+                self.salu32[int(a[0][1:])] = (self.salu32.get(int(a[1][1:]), 0) >> int(a[2], 0)) & M32
+            elif op == "s_getreg_b32":
+                assert "HW_REG_HW_ID" in rest
+                self.salu32[int(a[0][1:])] = getattr(self, "slot", 0) & 1
+            elif op == "s_xor_b32":
+                self.salu32[int(a[0][1:])] = self.salu32.get(int(a[1][1:]), 0) ^ self.salu32.get(int(a[2][1:]), 0)
+            elif op == "s_bitcmp1_b32":
+                scc = (self.salu32.get(int(a[0][1:]), 0) >> int(a[1], 0)) & 1
+            elif op == "s_setprio":
+                self.prio_log = getattr(self, "prio_log", [])
+                self.prio_log.append(int(a[0], 0))
             elif op == "s_and_b64":
                 bit = lambda o: getattr(self, "exec_bit", 1) if o.strip() == "exec" else self.s.get(self._key(o), 0)
                 kd = self._key(a[0])

@@ -383,6 +383,33 @@ def build_madd(tag=""):
     return gen
 
 
+# ---- fair turns for the waves of a SIMD: an experiment of round 4, OFF by default (profiles/r04/wave_timeline.txt) ----
+# The sequencer serves the oldest wave first: of the two waves of a SIMD the one in slot 0 takes ~70 % of the issue slots,
+# the two slot chains run in anti-phase from the first generation on, and the last wave of every SIMD finishes the kernel
+# ALONE (a lone wave issues every ~6 cycles instead of every 4): 0.7 ms of a 26.6 ms launch.  The user priority (s_setprio)
+# ranks above the age, so the waves could take TURNS at being favoured: a time slice of the 100 MHz counter every wave
+# reads (s_memrealtime), offset by the wave's slot on its SIMD.  In tools/arb_probe two waves of pure multiply-add code
+# finish after 1.56 / 2.98 ms without it and after 2.60 / 2.60 ms with it (kernel 3.06 -> 2.63 ms).  In ssa_k_verify, with
+# the priority refreshed once per doubling (SSA_GEN_FAIR=1: the counter is read at the top of a doubling and used at its
+# end) and in the compiled phases, the first generation's spread shrinks from 2.19-3.75 to 2.73-3.78 ms and the kernel
+# time does not move (26.70 against 26.65 ms); ssa_k_hash with four rotating priorities gets 4.6 % SLOWER.  Whatever
+# favours slot 0 in a kernel whose code does not fit the instruction buffers is not the issue arbitration alone.
+FAIR = os.environ.get("SSA_GEN_FAIR", "0") != "0"
+FAIR_SHIFT = int(os.environ.get("SSA_GEN_FAIR_SHIFT", "13"))
+
+
+def fair_read():
+    return ["s_memrealtime s[24:25]"] if FAIR else []
+
+
+def fair_set(tag):
+    if not FAIR:
+        return []
+    return ["s_waitcnt lgkmcnt(0)", "s_lshr_b32 s24, s24, %d" % FAIR_SHIFT, "s_getreg_b32 s21, hwreg(HW_REG_HW_ID, 0, 1)",
+            "s_xor_b32 s24, s24, s21", "s_bitcmp1_b32 s24, 0", "s_cbranch_scc1 L_%shi_%%=" % tag, "s_setprio 0",
+            "s_branch L_%sset_%%=" % tag, "L_%shi_%%=:" % tag, "s_setprio 1", "L_%sset_%%=:" % tag]
+
+
 def check_and_stats(gen, body, pinned):
     used = set(gen.al.used) | set(g6.POOL[:g6.N_FIXED + 4])
     for ln in body:
@@ -404,8 +431,8 @@ def asm_lines(out, body):
 
 def emit_dbl():
     gen = build_dbl()
-    pre = ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["s_mov_b32 s20, %[n]", "L_top_%=:"]
-    post = ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%=", "s_branch L_end_%="]
+    pre = ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["s_mov_b32 s20, %[n]", "L_top_%=:"] + fair_read()
+    post = fair_set("f") + ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%=", "s_branch L_end_%="]
     body = pre + gen.main + post + gen.cold + ["L_end_%=:"]
     used, n_valu, n_mad, n_nop = check_and_stats(gen, body, _pin_regs)
     out = ["// (X, Y, Z) <- [2^n](X, Y, Z), n >= 1, Jacobian, a = 1 (loose in / loose out; Z == 0 stays Z == 0).",
@@ -418,7 +445,7 @@ def emit_dbl():
             ops.append('"+{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
     out.append("        : " + ",\n          ".join(ops))
     out.append('        : [n] "s"(__builtin_amdgcn_readfirstlane(n))      // wave-uniform by contract')
-    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(21)] + ['"vcc"', '"scc"']
+    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(26 if FAIR else 21)] + ['"vcc"', '"scc"']
     out.append("        : " + ", ".join(clob) + ");")
     out.append("}")
     print("doubling: %d VALU (%d multiplies), %d s_nop; %d fixed VGPRs + 36 pinned; %d cold-path lines"
@@ -450,7 +477,7 @@ def emit_madd():
         for j in range(6):
             ins.append('"{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
     out.append("        : " + ",\n          ".join(ins))
-    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(21)] + ['"vcc"', '"scc"']
+    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(26 if FAIR else 21)] + ['"vcc"', '"scc"']
     out.append("        : " + ", ".join(clob) + ");")
     out += ["    return ok;", "}"]
     print("mixed addition: %d VALU (%d multiplies), %d s_nop; %d fixed VGPRs + 60 pinned; %d cold-path lines"
@@ -465,8 +492,8 @@ def emit_window():
     in_regs = set(r for p in gm.IN for r in (p, p + 1))
     assert not (set(gd.al.used) & in_regs)
     pinned = _pin_regs | in_regs
-    pre = ["v_mov_b32 v%d, 0" % r for r in gd.zero_regs] + ["v_mov_b32 %[ok], 1", "s_mov_b32 s20, %[n]", "L_top_%=:"]
-    loop_end = ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%="]
+    pre = ["v_mov_b32 v%d, 0" % r for r in gd.zero_regs] + ["v_mov_b32 %[ok], 1", "s_mov_b32 s20, %[n]", "L_top_%=:"] + fair_read()
+    loop_end = fair_set("f") + ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%="]
     narrow = ["v_cmp_ne_u32 vcc, 0, %[act]", "s_and_saveexec_b64 s[22:23], vcc", "s_cbranch_execz L_skip_%="]
     zero_m = ["v_mov_b32 v%d, 0" % r for r in gm.zero_regs if r not in gd.zero_regs]
     skip = ["L_skip_%=:", "s_mov_b64 exec, s[22:23]", "s_branch L_end_%="]
@@ -491,7 +518,7 @@ def emit_window():
         for j in range(6):
             ins.append('"{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
     out.append("        : " + ",\n          ".join(ins))
-    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(24)] + ['"vcc"', '"scc"']
+    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(26 if FAIR else 24)] + ['"vcc"', '"scc"']
     out.append("        : " + ", ".join(clob) + ");")
     out += ["    return ok;", "}"]
     print("window: %d fixed VGPRs + 60 pinned" % len(used))
