@@ -187,7 +187,7 @@ def test_generated_fp6_blocks_on_the_cpu():
     """every block of fp6_asm.inc (plain product / square and the fused product + linear-term blocks) through the
     interpreter, loose and edge operands, against plain integers; carry wait states checked on the way"""
     blocks = ai.extract_blocks(F6_INC)
-    assert len(blocks) == 9
+    assert len(blocks) == 11         # nine Fp6 blocks + the two Fp3 blocks (test_generated_fp3_blocks_on_the_cpu)
     rnd = random.Random(11)
     edge = [0, 1, P - 1, P, 2**64 - 1, 2**32 - 1, 2**32, 2**64 - 2**32]
 
@@ -246,6 +246,54 @@ def test_generated_fp6_blocks_on_the_cpu():
                 want = [(w + sign * c * t) % P for w, t in zip(want, arr[an])]
             assert got == want, (name, kind)
     assert cold_taken >= 12       # the sparse operands did take the reductions' cold path (negative result: - EPS there)
+
+
+def test_generated_fp3_blocks_on_the_cpu():
+    """the Fp3 = Fp[t]/(t^3 - 7) product and square of the square-root descent (fp3.hpp; round 4) through the interpreter:
+    loose, edge and sparse operands (k 2^48: the reductions' cold path) against plain integers"""
+    blocks = ai.extract_blocks(F6_INC)
+    rnd = random.Random(12)
+    edge = [0, 1, P - 1, P, 2**64 - 1, 2**32 - 1, 2**32, 2**64 - 2**32]
+
+    def elem(kind):
+        if kind == "edge":
+            return [rnd.choice(edge) for _ in range(3)]
+        if kind == "max":
+            return [2**64 - 1] * 3
+        if kind == "zero":
+            return [0] * 3
+        if kind == "sparse":
+            out = [0] * 3
+            out[rnd.randrange(3)] = rnd.randrange(1, 2**16) << 48
+            return out
+        return [rnd.randrange(2**64) for _ in range(3)]
+
+    def mulmod(u, v):
+        t = [0] * 5
+        for i, x in enumerate(u):
+            for j, y in enumerate(v):
+                t[i + j] += x * y
+        return [(t[k] + 7 * (t[k + 3] if k + 3 < 5 else 0)) % P for k in range(3)]
+
+    cold_taken = 0
+    for name, is_sqr in (("f3_mul_core_asm", False), ("f3_sqr_core_asm", True)):
+        lines, outs, ins = blocks[name]
+        for kind in ["rand"] * 8 + ["edge"] * 6 + ["max", "zero"] + ["sparse"] * 8:
+            arr = {"a": elem(kind), "b": elem("rand" if kind == "zero" else kind)}
+            arr["b7"] = [7 * t % P for t in arr["b"]]
+            arr["a2"] = [2 * t % P for t in arr["a"]]
+            arr["a7"] = [7 * t % P for t in arr["a"]]
+            arr["a14"] = [14 * t % P for t in arr["a"]]
+            env = {}
+            for nm, (half, an, idx) in ins.items():
+                val = arr[an][idx]
+                env["%%[%s]" % nm] = val & M32 if half == "lo32" else val >> 32
+            lane = ai.Lane(env, dummy_pairs=())
+            e = lane.run(lines)
+            cold_taken += any(lb.endswith("_fix_%=") for lb in getattr(lane, "visited", ()))
+            got = [(e["%%[r%dl]" % k] | (e["%%[r%dh]" % k] << 32)) % P for k in range(3)]
+            assert got == mulmod(arr["a"], arr["a"] if is_sqr else arr["b"]), (name, kind)
+    assert cold_taken >= 4
 
 
 def test_asm_blocks_declare_what_they_clobber():

@@ -336,6 +336,72 @@ def emit(name, terms, inputs, doc, extras=()):
     return out, len(lines), nm
 
 
+# ---- Fp3 = Fp[t]/(t^3 - 7): the product and the square of the square-root descent (fp3.hpp, round 4) -------------------
+# One group of three accumulators, one reduce3.  The compiled f3_mul (fp_acc in C++) costs ~190 instructions and served as
+# the square too (9 products); here the product is 9 x 8 + 33 and the square 6 x 8 + 33 instructions.
+def f3_mul_terms():
+    """c_k = sum_{i+j=k} a_i b_j + sum_{i+j=k+3} a_i (7 b_j)"""
+    return [[("a0", "b0"), ("a1", "s2"), ("a2", "s1")],
+            [("a0", "b1"), ("a1", "b0"), ("a2", "s2")],
+            [("a0", "b2"), ("a1", "b1"), ("a2", "b0")]]
+
+
+def f3_sqr_terms():
+    """c_0 = a0^2 + a1 (14 a2), c_1 = a0 (2 a1) + a2 (7 a2), c_2 = a0 (2 a2) + a1^2"""
+    return [[("a0", "a0"), ("a1", "t2")],
+            [("a0", "d1"), ("a2", "s2")],
+            [("a0", "d2"), ("a1", "a1")]]
+
+
+def emit3(name, terms, inputs, doc):
+    accs = [Acc(j) for j in range(3)]
+    lines = []
+    for k in range(3):
+        t = terms[k]
+        lines += init2(accs[k], t[0][0], t[0][1], t[1][0], t[1][1], None)
+        for x, y in t[2:]:
+            lines += mac(accs[k], x, y)
+    # the inputs are dead once the last product is issued, but an output operand may share a register with an input the
+    # compiler still needs: the results wait in the parking registers until the end, as in the six-coefficient blocks
+    outs = [("v%d" % RES[2 * j], "v%d" % RES[2 * j + 1]) for j in range(3)]
+    hot, cold = reduce3(accs, outs, "r0")
+    lines += hot
+    for j in range(3):
+        lines.append("v_mov_b32 %%[r%dl], v%d" % (j, RES[2 * j]))
+        lines.append("v_mov_b32 %%[r%dh], v%d" % (j, RES[2 * j + 1]))
+    lines += ["s_branch L_end_%="] + cold + ["L_end_%=:"]
+    used = set()
+    for ln in lines:
+        for tok in ln.replace(",", " ").split():
+            if tok.startswith("%["):
+                used.add(tok[2:-1])
+    out = ["// %s" % doc, "SSA_DEV void %s(%s, u64 (&r)[3]) {" % (name, ", ".join("const u64 (&%s)[3]" % n for n, _ in inputs))]
+    out.append("    u32 " + ", ".join("r%dl, r%dh" % (j, j) for j in range(3)) + ";")
+    out.append("    asm(")
+    for i, ln in enumerate(lines):
+        out.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(lines) else ""))
+    outs = []
+    for j in range(3):
+        outs.append('[r%dl] "=v"(r%dl)' % (j, j))
+        outs.append('[r%dh] "=v"(r%dh)' % (j, j))
+    out.append("        : " + ", ".join(outs))
+    ins = []
+    for arr, prefix in inputs:
+        for j in range(3):
+            nm = "%s%d" % (prefix, j)
+            if nm + "l" in used or nm + "h" in used:
+                ins.append('[%sl] "v"(lo32(%s[%d]))' % (nm, arr, j))
+                ins.append('[%sh] "v"(hi32(%s[%d]))' % (nm, arr, j))
+    out.append("        : " + ",\n          ".join(ins))
+    clob = ['"v%d"' % r for r in POOL[:N_FIXED]] + ['"s%d"' % i for i in range(20)] + ['"vcc"', '"scc"']
+    out.append("        : " + ", ".join(clob) + ");")
+    for j in range(3):
+        out.append("    r[%d] = mk64(r%dl, r%dh);" % (j, j, j))
+    out.append("}")
+    nm = sum(1 for ln in lines if ln.startswith("v_mad"))
+    return out, len(lines), nm
+
+
 OUT_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc", "fp6_asm.inc")
 
 
@@ -365,7 +431,15 @@ def generate():
         blk, nl, nmad = emit(nm, terms, ins, doc, ex)
         print("%s: %d instructions, %d mads" % (nm, nl, nmad))
         fused += [""] + blk
-    return "\n".join(hdr + m + [""] + s + fused) + "\n"
+    f3 = []
+    for nm, terms, ins, doc in (
+            ("f3_mul_core_asm", f3_mul_terms(), [("a", "a"), ("b", "b"), ("b7", "s")], "r = a * b in Fp[t]/(t^3 - 7); b7[j] = 7 b[j] (j = 1, 2)"),
+            ("f3_sqr_core_asm", f3_sqr_terms(), [("a", "a"), ("a2", "d"), ("a7", "s"), ("a14", "t")],
+             "r = a^2 in Fp[t]/(t^3 - 7); a2[j] = 2 a[j] (j = 1, 2), a7[2] = 7 a[2], a14[2] = 14 a[2]")):
+        blk, nl, nmad = emit3(nm, terms, ins, doc)
+        print("%s: %d instructions, %d mads" % (nm, nl, nmad))
+        f3 += [""] + blk
+    return "\n".join(hdr + m + [""] + s + fused + f3) + "\n"
 
 
 def main():
