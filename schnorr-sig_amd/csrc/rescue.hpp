@@ -109,6 +109,24 @@ SSA_DEV u64 sbox_block(u64 *const (&p)[SSA_FP_CHAINS]) {
 #endif
     return st;
 }
+// ONE value: the cooperative kernels' sponge (a state element per lane of one wave: latency, not throughput).  The single-chain
+// programs pad the wait states of their carries with s_nop: 811 + 288 issue slots for x^(1/7) where the compiled chain has
+// ~1800; a lane the block flags is recomputed from its input.
+template <bool INV>
+SSA_DEV u64 sbox_one(u64 x) {
+#ifdef SSA_FP_CHAIN_ASM
+    u64 v = x, st = 0;
+    if (INV) inv_sbox_1_asm(v, st);
+    else sbox_1_asm(v, st);
+    if (st != 0) {
+        if (lane_bit(st)) v = INV ? inv_sbox(x) : sbox(x);
+    }
+    return v;
+#else
+    return INV ? inv_sbox(x) : sbox(x);
+#endif
+}
+
 // the S-box layer of the 12-element state at `st` (element i at st[i * RS_STRIDE]): blocks (i, i + n, i + 2n), n = 12 / chains
 template <bool INV>
 SSA_DEV void sbox_layer(u64 *state, int stride) {

@@ -424,7 +424,7 @@ COOP_FN void coop_rescue_permutation(CoopLds &L, const DevParams *__restrict__ p
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             u64 *src = half ? T : S, *dst = half ? S : T;
-            if (lane < 12) src[lane] = half ? inv_sbox(src[lane]) : sbox(src[lane]);
+            if (lane < 12) src[lane] = half ? sbox_one<true>(src[lane]) : sbox_one<false>(src[lane]);
             coop_sync();
             if (lane < 12) {
                 const u64 *row = prm->mds + lane * 12;

@@ -24,35 +24,38 @@ F6_INC = os.path.join(os.path.dirname(INC), "fp6_asm.inc")
 def run(txt_blocks, fn, vals):
     """-> ([x', ...], flag): the values of the block's chains (PINNED to the chains' value registers) after the program, and
     this lane's bit of the mask operand %[st] -- non-zero means a reduction met its rare borrow and the values are to be
-    recomputed by the caller"""
+    recomputed by the caller.  The block size is the number of values (the *_n_asm programs: NCH, the *_1_asm programs: 1)"""
     import gen_fp_chain_asm as g
     lines, outs, _ = txt_blocks[fn]
-    assert len(vals) == g.NCH
+    nch = len(vals)
+    assert nch == (1 if fn.endswith("_1_asm") else g.NCH)
     lane = ai.Lane({}, dummy_pairs=(g.DUMMY,))
     for c, x in enumerate(vals):
-        r = g.regs(c)["X"]
+        r = g.regs(c, nch)["X"]
         lane.v[r], lane.v[r + 1] = x & M32, x >> 32
     lane.run(lines)
-    out = [lane.v[g.regs(c)["X"]] | (lane.v[g.regs(c)["X"] + 1] << 32) for c in range(g.NCH)]
+    out = [lane.v[g.regs(c, nch)["X"]] | (lane.v[g.regs(c, nch)["X"] + 1] << 32) for c in range(nch)]
     return out, lane.s.get("%[st]", 0)
 
 
 def test_generated_sbox_asm_on_the_cpu():
     import gen_fp_chain_asm as g
     txt = ai.extract_blocks(INC)
-    assert set(txt) == {"inv_sbox_n_asm", "sbox_n_asm"}
+    assert set(txt) == {"inv_sbox_n_asm", "sbox_n_asm", "inv_sbox_1_asm", "sbox_1_asm"}
     rnd = random.Random(5)
     e_inv = 10540996611094048183          # 7^-1 mod (p - 1)
     vals = [0, 1, P - 1, P, P + 1, 2**64 - 1, 2**32, 2**32 - 1, 2**63, 2**64 - 2**32] + [rnd.randrange(2**64) for _ in range(30)]
     flagged = 0
     for i, a in enumerate(vals):
         ins = [vals[(i * (7 + 4 * c) + 3 * c) % len(vals)] for c in range(g.NCH)]
-        for fn, want in (("inv_sbox_n_asm", lambda v: pow(v, e_inv, P)), ("sbox_n_asm", lambda v: pow(v, 7, P))):
-            got, fl = run(txt, fn, ins)
+        for fn, want in (("inv_sbox_n_asm", lambda v: pow(v, e_inv, P)), ("sbox_n_asm", lambda v: pow(v, 7, P)),
+                         ("inv_sbox_1_asm", lambda v: pow(v, e_inv, P)), ("sbox_1_asm", lambda v: pow(v, 7, P))):
+            vals_in = ins[:1] if fn.endswith("_1_asm") else ins
+            got, fl = run(txt, fn, vals_in)
             flagged += bool(fl)
             # a flagged lane is recomputed by the caller; an unflagged one must be right
-            assert fl or [v % P for v in got] == [want(v) for v in ins], (fn, [hex(v) for v in ins])
-    assert flagged <= 8          # only the hand-picked edge values can get there (2^32 * 2^32 = 2^64, ...)
+            assert fl or [v % P for v in got] == [want(v) for v in vals_in], (fn, [hex(v) for v in vals_in])
+    assert flagged <= 16         # only the hand-picked edge values can get there (2^32 * 2^32 = 2^64, ...)
 
 
 def test_sbox_programs_execute_no_copy_and_no_loop():
@@ -68,6 +71,11 @@ def test_sbox_programs_execute_no_copy_and_no_loop():
         movs = [ln for ln in valu if ln.startswith("v_mov_b32")]
         assert len(movs) == g.NCH * (1 + 4 * n_mul), (fn, len(movs))                    # only the product head's four word moves
         assert not any(ln.startswith("s_nop") for ln in lines), fn
+    # the single-chain programs of the cooperative kernels: the same arithmetic, wait states padded with s_nop
+    for fn, n_sq, n_mul in (("inv_sbox_1_asm", 63, 9), ("sbox_1_asm", 2, 2)):
+        lines = txt[fn][0]
+        assert len([ln for ln in lines if ln.startswith("v_")]) == 11 * n_sq + 13 * n_mul + 1, fn
+        assert not any(ln.startswith(("s_cbranch", "s_branch")) or ln.endswith(":") for ln in lines), fn
 
 
 def test_sbox_asm_reports_the_rare_borrow():
@@ -84,6 +92,8 @@ def test_sbox_asm_reports_the_rare_borrow():
                 ins[c] = a
                 assert run(txt, fn, ins)[1] == 1, (fn, k, c)
             assert run(txt, fn, [5 + j for j in range(g.NCH)])[1] == 0
+        for fn in ("inv_sbox_1_asm", "sbox_1_asm"):
+            assert run(txt, fn, [a])[1] == 1 and run(txt, fn, [5])[1] == 0, (fn, k)
 
 
 def test_reduction_tail_is_exact_or_flagged():

@@ -42,11 +42,14 @@ N_PAIRS = 13      # T A U H M E C + the six value pairs X V0..V4
 BASE = 128 - 2 * NCH * N_PAIRS      # all above the compiler's own allocation for ssa_k_hash, all below v128
 
 
-def regs(c):
-    """chain c's register pairs (interleaved with the other chains': pair k of chain c is BASE + 2 c + 2 NCH k) and its three
-    carry pairs S, S2, S3 (s32 / s33 are the stack and frame pointers)"""
+def regs(c, nch=None):
+    """chain c's register pairs (interleaved with the other chains': pair k of chain c is BASE + 2 c + 2 n k for a block of n
+    chains, the block ending at v127) and its three carry pairs S, S2, S3 (s32 / s33 are the stack and frame pointers)"""
+    n = NCH if nch is None else nch
+    base = 128 - 2 * n * N_PAIRS
+
     def pair(k):
-        return BASE + 2 * c + 2 * NCH * k
+        return base + 2 * c + 2 * n * k
 
     g = {"X": pair(0), "T": pair(1), "A": pair(2), "U": pair(3), "H": pair(4), "M": pair(5), "E": pair(6), "C": pair(7),
          "S": 20 + 2 * c, "S2": 26 + 2 * c, "S3": 36 + 2 * c}
@@ -64,6 +67,7 @@ MOVES_HEAD = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "carries"       # "m
 SQ_MERGE_FAST = os.environ.get("SSA_GEN_SQ_MERGE", "") == "fast"
 MUL_HEAD_ADD1 = os.environ.get("SSA_GEN_MUL_HEAD", "moves") != "moves10"     # round 4 default; "moves10" = round 3's head
 DUMMY = "s[42:43]"     # carry-outs nobody reads
+CUR_NCH = [None]       # chains of the block being generated (None: NCH); square() / multiply() read their registers through it
 SGPRS = list(range(20, 32)) + list(range(36, 44))
 
 
@@ -79,7 +83,7 @@ def square(c, src=None, dst=None, st=None):
     """(text, sgprs read, sgprs written) of one squaring of chain c, in dependency order.  src / dst: the register pairs
     the value is read from and written to (default: in place in X); st: the asm operand that collects the rare-borrow
     lanes (default: the chain's own sticky pair)"""
-    g = regs(c)
+    g = regs(c, CUR_NCH[0])
     X, T, A, U, H, M, E, C, S, S2, S3 = (g[k] for k in ("X", "T", "A", "U", "H", "M", "E", "C", "S", "S2", "S3"))
     XS = X if src is None else src          # the three products read the source pair ...
     X = X if dst is None else dst           # ... the reduction writes the destination pair
@@ -123,7 +127,7 @@ def multiply(c, saved, src=None, dst=None, st=None):
     zero-extended pairs (v[A+1] and v[C+1] hold 0), then the reduction.  The alternative below the early return -- the
     65-bit middle sum's carry k riding into the top product as the addend (0, k), a three-instruction carry chain for the
     halves: 8 instructions instead of 10 -- measured slower (see MOVES_HEAD)."""
-    g = regs(c)
+    g = regs(c, CUR_NCH[0])
     X, T, A, U, H, C, E, V, S = g["X"], g["T"], g["A"], g["U"], g["H"], g["C"], g["E"], g[saved] if isinstance(saved, str) else saved, g["S"]
     if src is not None:
         X = src                 # the head reads the source pair; the reduction writes dst (reduce_tail)
@@ -248,16 +252,17 @@ def rename(prog):
     return out
 
 
-ARGS = ["x", "y", "z", "w"][:NCH]
-
-
-def emit_program(name, prog, doc):
-    gs = [regs(c) for c in range(NCH)]
+def emit_program(name, prog, doc, nch=None):
+    nch = NCH if nch is None else nch
+    CUR_NCH[0] = nch
+    args = ["x", "y", "z", "w"][:nch]
+    base = 128 - 2 * nch * N_PAIRS
+    gs = [regs(c, nch) for c in range(nch)]
     lines = ["// %s" % doc,
              "// The values are pinned to the blocks' own value registers (no moves in or out; the compiler loads the state",
              "// straight into them); st collects the lanes (bit per lane) where a reduction met its rare borrow: their values are",
              "// then WRONG and the caller recomputes them from its inputs with the compiled exact code (rescue.hpp)",
-             "SSA_DEV void %s(%s, u64 &st) {" % (name, ", ".join("u64 &" + a for a in ARGS)), "    asm volatile("]
+             "SSA_DEV void %s(%s, u64 &st) {" % (name, ", ".join("u64 &" + a for a in args)), "    asm volatile("]
     body = []
     for g in gs:
         body += zero_inits(g)
@@ -276,14 +281,15 @@ def emit_program(name, prog, doc):
         counts["nop"] += sum(1 for ln in seg if ln.startswith("s_nop"))
     for i, ln in enumerate(body):
         lines.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(body) else ""))
-    lines.append("        : " + ", ".join('"+{v[%d:%d]}"(%s)' % (g["X"], g["X"] + 1, a) for g, a in zip(gs, ARGS)) + ', [st] "+s"(st)')
+    lines.append("        : " + ", ".join('"+{v[%d:%d]}"(%s)' % (g["X"], g["X"] + 1, a) for g, a in zip(gs, args)) + ', [st] "+s"(st)')
     lines.append("        :")
     pinned = {r for g in gs for r in (g["X"], g["X"] + 1)}
-    clob = ['"v%d"' % r for r in range(BASE, BASE + 2 * NCH * N_PAIRS) if r not in pinned] + ['"s%d"' % r for r in SGPRS] + \
+    clob = ['"v%d"' % r for r in range(base, base + 2 * nch * N_PAIRS) if r not in pinned] + ['"s%d"' % r for r in SGPRS] + \
         ['"scc"', '"vcc"']
     lines.append("        : " + ", ".join(clob) + ");")
     lines += ["}"]
-    print("%s: %d VALU instructions + %d s_nop for the %d values" % (name, counts["valu"], counts["nop"], NCH))
+    print("%s: %d VALU instructions + %d s_nop for the %d value%s" % (name, counts["valu"], counts["nop"], nch, "" if nch == 1 else "s"))
+    CUR_NCH[0] = None
     return lines
 
 
@@ -413,7 +419,12 @@ def generate():
     progs = emit_program("inv_sbox_n_asm", INV_SBOX, "x <- x^(1/7) for %d values: the whole 63-squaring / 9-product chain of "
                          "all of them in one block, interleaved" % NCH) + [""] + \
         emit_program("sbox_n_asm", SBOX, "x <- x^7 for %d values" % NCH)
-    return "\n".join(lines + progs) + "\n"
+    # ONE value per block: the latency path (ssa_coop.hpp: the sponge state on 12 lanes of one wave, a lane per element).  A
+    # lone chain cannot fill the wait states of its SGPR carries with another chain's instructions: s_nop where nothing
+    # else is ready (4 per squaring) -- still 11 + 4 issue slots where the compiled squaring has 22 + 2.
+    single = emit_program("inv_sbox_1_asm", INV_SBOX, "x <- x^(1/7) for ONE value (the cooperative kernels' sponge)", 1) + [""] + \
+        emit_program("sbox_1_asm", SBOX, "x <- x^7 for ONE value", 1)
+    return "\n".join(lines + progs + [""] + single) + "\n"
 
 
 def main():
