@@ -182,6 +182,8 @@ class Gen:
             nm, half = mo.group(1), mo.group(2)
             return "v%d" % (m[nm] + (1 if half == "h" else 0))
         self.main += [re.sub(r"%\[(\w+?)([lh])\]", sub, ln) for ln in lines]
+        self.nfair = getattr(self, "nfair", 0) + 1
+        self.main += fair_now("%sq%d" % (self.tag, self.nfair))
 
     # ---- dst = (2)a - b coefficient-wise (a = None: -b); one guard: the doubling needs a's high word below all ones,
     # the second borrow of the subtraction b's ----
@@ -394,12 +396,17 @@ def build_madd(tag=""):
 # end) and in the compiled phases, the first generation's spread shrinks from 2.19-3.75 to 2.73-3.78 ms and the kernel
 # time does not move (26.70 against 26.65 ms); ssa_k_hash with four rotating priorities gets 4.6 % SLOWER.  Whatever
 # favours slot 0 in a kernel whose code does not fit the instruction buffers is not the issue arbitration alone.
-FAIR = os.environ.get("SSA_GEN_FAIR", "0") != "0"
+FAIR = int(os.environ.get("SSA_GEN_FAIR", "0"))      # 0 off, 1 once per doubling, 2 after every Fp6 block (~400 instructions)
 FAIR_SHIFT = int(os.environ.get("SSA_GEN_FAIR_SHIFT", "13"))
 
 
 def fair_read():
     return ["s_memrealtime s[24:25]"] if FAIR else []
+
+
+def fair_now(tag):
+    """read the clock and set the priority on the spot (FAIR = 2: between two Fp6 blocks)"""
+    return ["s_memrealtime s[24:25]"] + fair_set(tag) if FAIR >= 2 else []
 
 
 def fair_set(tag):
