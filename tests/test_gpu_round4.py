@@ -105,6 +105,17 @@ def test_bench_line_names_its_flags_and_cpu_leg_runs_them():
     assert cb["flags"] == 8 and cb["agrees_with_gpu"] is True and "SSA_FLAG_SIG_FLAG_BYTE" in cb["sample"]
 
 
+def test_bench_pipelined_leg_verifies_what_the_metric_verifies():
+    """`pipelined_two_contexts` (two contexts of the device over the halves of every batch: what a caller that pipelines batches
+    gets) rejects exactly the corrupted signatures of the batch the timed steps ran on, and is reported beside the metric"""
+    out = _bench(["--gpus", "1", "--batch", "65536", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--corrupt", "0.01"])
+    leg = out["pipelined_two_contexts"]
+    assert "error" not in leg, leg
+    assert leg["rejected"] == out["rejected"] == 655
+    assert leg["verifications_per_sec"] > 0 and "not the metric" in leg["note"]
+    assert out["all_verdicts_as_expected"] is True
+
+
 # ---------------------------------------------------------------- bounded workspaces: slices of a fixed lane count
 def _sliced_engine(lane=65536, msm=65536):
     """an engine whose per-lane kernels / MSM pipeline run over slices of the given size (read at ssa_ctx_create)"""
