@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(512, 1) k_arb(int iters, int mode, int period,
         const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
         out[3 * w] = t0;
         out[3 * w + 1] = t1;
-        out[3 * w + 2] = slot | ((unsigned long long)(x & 1u) << 32);
+        out[3 * w + 2] = slot | ((unsigned long long)(x & 1u) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u) << 8);
     }
 }
 
@@ -74,6 +74,18 @@ int main(int argc, char **argv) {
         }
         std::printf("%-34s slot 0: %8.1f us (%d waves)   slot 1: %8.1f us (%d waves)   kernel span %8.1f us\n", r.name,
                     dur[0] / (cnt[0] ? cnt[0] : 1), cnt[0], dur[1] / (cnt[1] ? cnt[1] : 1), cnt[1], (double)(tmax - tmin) / 100.0);
+        if (r.mode == 0) {      // per XCD: the mean life of a PAIR of waves (slot 0 + slot 1: the SIMD's work), pure arithmetic
+            double sum[8] = {0};
+            int c8[8] = {0};
+            for (size_t w = 0; w < nw; w++) {
+                const int xcc = (int)((h[3 * w + 2] >> 8) & 7u);
+                sum[xcc] += (double)(h[3 * w + 1] - h[3 * w]) / 100.0;
+                c8[xcc]++;
+            }
+            std::printf("    per XCC, mean wave life (us):");
+            for (int x = 0; x < 8; x++) std::printf(" %d: %.1f", x, c8[x] ? sum[x] / c8[x] : 0.0);
+            std::printf("\n");
+        }
     }
     return 0;
 }
