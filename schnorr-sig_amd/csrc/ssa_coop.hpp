@@ -167,11 +167,17 @@ COOP_FN u64 coop_group_mul(const u64 *A, const u64 *B, u32 k, u32 q) {
         x[j] = A[i];
         y[j] = B[idx];
     }
+#if defined(SSA_F6_ASM) && COOP_LPC == 2 && !defined(SSA_NO_ACC3_ASM)
+    // round 4: the lane's three products and their reduction as one generated block (fp6_asm.inc fp_acc3_core_asm: 32
+    // instructions + 7 padded wait states; the compiled fp_acc sequence is ~58) -- this is the critical path of every round
+    u64 r = fp_acc3_core_asm(x, y);
+#else
     fp_acc acc;
     acc_init(acc, x[0], y[0]);
 #pragma unroll
     for (int j = 1; j < NT; j++) acc_mac(acc, x[j], y[j]);
     u64 r = acc_reduce(acc);
+#endif
 #if COOP_LPC == 2
     r = fp_add(r, coop_swap_neighbour(r));
 #endif

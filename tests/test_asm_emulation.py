@@ -197,7 +197,8 @@ def test_generated_fp6_blocks_on_the_cpu():
     """every block of fp6_asm.inc (plain product / square and the fused product + linear-term blocks) through the
     interpreter, loose and edge operands, against plain integers; carry wait states checked on the way"""
     blocks = ai.extract_blocks(F6_INC)
-    assert len(blocks) == 11         # nine Fp6 blocks + the two Fp3 blocks (test_generated_fp3_blocks_on_the_cpu)
+    assert len(blocks) == 11         # nine Fp6 blocks + the two Fp3 blocks (test_generated_fp3_blocks_on_the_cpu); the
+    # single-accumulator block returns u64 and is read by test_generated_acc3_block_on_the_cpu
     rnd = random.Random(11)
     edge = [0, 1, P - 1, P, 2**64 - 1, 2**32 - 1, 2**32, 2**64 - 2**32]
 
@@ -306,6 +307,41 @@ def test_generated_fp3_blocks_on_the_cpu():
     assert cold_taken >= 4
 
 
+def test_generated_acc3_block_on_the_cpu():
+    """fp_acc3_core_asm (one lane's three products of a cooperative Fp6 product round, one padded reduction): random, edge and
+    sparse operands (k 2^48 pairs: the reduction's cold path) against plain integers; wait states enforced by the interpreter"""
+    txt = open(F6_INC).read()
+    m = re.search(r"SSA_DEV u64 fp_acc3_core_asm\(.*?asm\(\n(.*?)\n        : ", txt, re.S)
+    lines = [ln.strip().strip('"').replace("\\n\\t", "") for ln in m.group(1).split("\n") if ln.strip()]
+    rnd = random.Random(13)
+    edge = [0, 1, P - 1, P, 2**64 - 1, 2**32 - 1, 2**32, 2**64 - 2**32]
+    cold = 0
+    for it in range(60):
+        if it < 25:
+            x = [rnd.randrange(2**64) for _ in range(3)]
+            y = [rnd.randrange(2**64) for _ in range(3)]
+        elif it < 40:
+            x = [rnd.choice(edge) for _ in range(3)]
+            y = [rnd.choice(edge) for _ in range(3)]
+        elif it == 40:
+            x, y = [2**64 - 1] * 3, [2**64 - 1] * 3
+        else:
+            x, y = [0] * 3, [0] * 3
+            j = rnd.randrange(3)
+            x[j], y[j] = rnd.randrange(1, 2**16) << 48, rnd.randrange(1, 2**16) << 48
+        env = {}
+        for nm, arr in (("x", x), ("y", y)):
+            for j in range(3):
+                env["%%[%s%dl]" % (nm, j)] = arr[j] & M32
+                env["%%[%s%dh]" % (nm, j)] = arr[j] >> 32
+        lane = ai.Lane(env, dummy_pairs=())
+        e = lane.run(lines)
+        cold += any(lb.startswith("L_fix") for lb in getattr(lane, "visited", ()))
+        got = (e["%[rl]"] | (e["%[rh]"] << 32)) % P
+        assert got == sum(a * b for a, b in zip(x, y)) % P, (it, x, y)
+    assert cold >= 5
+
+
 def test_asm_blocks_declare_what_they_clobber():
     """A scalar ALU instruction inside a block (s_andn2_b64, s_sub_u32, s_cmp_*) rewrites SCC: the block must say so,
     or the compiler keeps a loop condition alive across it (a GPU hang in round 2 before the clobber was added).
@@ -313,7 +349,7 @@ def test_asm_blocks_declare_what_they_clobber():
     import re
     for path in (INC, F6_INC):
         txt = open(path).read()
-        for m in re.finditer(r"SSA_DEV (?:void|u32) (\w+)\(.*?asm(?: volatile)?\(\n(.*?)\n        : (.*?)\n        :(.*?)\n        : (\".*?)\);", txt, re.S):
+        for m in re.finditer(r"SSA_DEV (?:void|u32|u64) (\w+)\(.*?asm(?: volatile)?\(\n(.*?)\n        : (.*?)\n        :(.*?)\n        : (\".*?)\);", txt, re.S):
             name, body, clob = m.group(1), m.group(2), m.group(5)
             clobbers = set(re.findall(r'"(\w+)"', clob))
             # registers an operand is PINNED to ("+{v[72:73]}"(x)) are declared by the operand, and must not be clobbers too

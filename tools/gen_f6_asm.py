@@ -402,6 +402,69 @@ def emit3(name, terms, inputs, doc):
     return out, len(lines), nm
 
 
+# ---- one accumulator: r = x0 y0 + x1 y1 + x2 y2 (mod p) -- what ONE lane of the cooperative kernels computes per product
+# round (ssa_coop.hpp coop_group_mul: twelve lanes per Fp6 product, three terms each).  The latency path: the reduction
+# of a single chain cannot fill the wait states of its carries with a neighbour's instructions, so they are padded (s_nop).
+def pad_wait_states(lines, gap=3):
+    """insert s_nop so that a VALU read of an SGPR pair / VCC comes at least `gap` positions after its VALU write"""
+    import re
+    out, written = [], {}
+    for ln in lines:
+        if ln.startswith("v_"):
+            ops = [o.strip() for o in ln.split(None, 1)[1].split(",")]
+            mnem = ln.split()[0]
+            n_dst = 2 if mnem in ("v_mad_u64_u32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subbrev_co_u32") else 1
+            reads = [o for o in ops[n_dst:] if re.match(r"(s\[\d+:\d+\]|vcc)$", o)]
+            need = 0
+            for r in reads:
+                if r in written:
+                    need = max(need, gap - (len(out) - written[r]))
+            if need > 0:
+                out.append("s_nop %d" % (need - 1))
+                # an s_nop N occupies one position and N + 1 wait states: account for it as `need` positions
+                for k in list(written):
+                    written[k] -= need - 1
+            out.append(ln)
+            if n_dst == 2 and re.match(r"(s\[\d+:\d+\]|vcc)$", ops[1]):
+                written[ops[1]] = len(out) - 1
+        else:
+            out.append(ln)
+    return out
+
+
+def emit_acc3(name, doc):
+    acc = Acc(0)
+    lines = init2(acc, "x0", "y0", "x1", "y1", None) + mac(acc, "x2", "y2")
+    m = {"c0p": acc.pair(0), "c0l": acc.lo(0), "c0h": acc.hi(0), "c1l": acc.lo(1), "c1h": acc.hi(1), "c2l": acc.lo(2),
+         "c2h": acc.hi(2), "k0": acc.kk(0), "k1": acc.kk(1), "k2": acc.kk(2), "A": "s[0:1]", "B": "s[2:3]", "T": "s[14:15]",
+         "outl": "%[rl]", "outh": "%[rh]"}
+    red = [st.format(**m) for st in REDUCE_STEPS]
+    lines = pad_wait_states(lines + red)
+    # the rare negative result (mask T, SCC from s_andn2): - EPS = + (1, 2^32 - 1) in the flagged lanes
+    lines += ["s_cbranch_scc1 L_fix_%=", "L_back_%=:", "s_branch L_end_%=", "L_fix_%=:",
+              "v_cndmask_b32_e64 {k0}, 0, 1, {T}".format(**m), "v_cndmask_b32_e64 {k1}, 0, -1, {T}".format(**m),
+              "v_add_co_u32 %[rl], {A}, %[rl], {k0}".format(**m), "s_nop 1",
+              "v_addc_co_u32 %[rh], {A}, %[rh], {k1}, {A}".format(**m), "s_branch L_back_%=", "L_end_%=:"]
+    out = ["// %s" % doc, "SSA_DEV u64 %s(const u64 (&x)[3], const u64 (&y)[3]) {" % name, "    u32 rl, rh;", "    asm("]
+    for i, ln in enumerate(lines):
+        out.append('        "%s%s"' % (ln, "\\n\\t" if i + 1 < len(lines) else ""))
+    out.append('        : [rl] "=&v"(rl), [rh] "=&v"(rh)')
+    ins = []
+    for arr in ("x", "y"):
+        for j in range(3):
+            ins.append('[%s%dl] "v"(lo32(%s[%d]))' % (arr, j, arr, j))
+            ins.append('[%s%dh] "v"(hi32(%s[%d]))' % (arr, j, arr, j))
+    out.append("        : " + ",\n          ".join(ins))
+    fixed = sorted(set(r for pr in acc.c for r in pr) | set(acc.k))
+    clob = ['"v%d"' % r for r in fixed] + ['"s%d"' % i for i in (0, 1, 2, 3, 4, 5, 14, 15)] + ['"vcc"', '"scc"']
+    out.append("        : " + ", ".join(clob) + ");")
+    out += ["    return mk64(rl, rh);", "}"]
+    n_valu = sum(1 for ln in lines if ln.startswith("v_"))
+    n_nop = sum(int(ln.split()[1]) + 1 for ln in lines if ln.startswith("s_nop"))
+    print("%s: %d VALU instructions on the hot path + %d wait states" % (name, n_valu - 4, n_nop - 2))
+    return out
+
+
 OUT_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schnorr-sig_amd", "csrc", "fp6_asm.inc")
 
 
@@ -439,7 +502,8 @@ def generate():
         blk, nl, nmad = emit3(nm, terms, ins, doc)
         print("%s: %d instructions, %d mads" % (nm, nl, nmad))
         f3 += [""] + blk
-    return "\n".join(hdr + m + [""] + s + fused + f3) + "\n"
+    acc3 = [""] + emit_acc3("fp_acc3_core_asm", "r = x0 y0 + x1 y1 + x2 y2 (mod p, loose): one lane's share of a cooperative Fp6 product")
+    return "\n".join(hdr + m + [""] + s + fused + f3 + acc3) + "\n"
 
 
 def main():
