@@ -660,6 +660,10 @@ class PublicKey:
         return signature.verify(message, self)
 
     @classmethod
+    def from_private(cls, sk, engine=None):  # impl From<&PrivateKey> for PublicKey, src/public.rs:26-32: [sk]G on the GPU
+        return KeyPair.from_private(sk, engine).public_key
+
+    @classmethod
     def from_bytes(cls, b49, engine=None):
         """PublicKey::from_bytes (src/public.rs:54-56): None when decompression fails.  The identity
         encoding decodes to a key whose affine bytes are zero and `is_identity` is set."""
@@ -702,6 +706,36 @@ class PrivateKey:
 
     def to_bytes(self):
         return self.bytes
+
+    @classmethod
+    def from_bytes(cls, b32):  # src/private.rs:74-76: None (CtOption is_none) for a non-canonical or zero scalar
+        b = bytes(b32)
+        if len(b) != PRIVATE_KEY_LENGTH:
+            raise ValueError("private key needs 32 bytes")
+        v = int.from_bytes(b, "little")
+        return None if v == 0 or v >= Q else cls(b)
+
+    @classmethod
+    def from_seed(cls, seed64):  # src/private.rs:79-82: Scalar::from_bytes_wide, None for 0
+        b = bytes(seed64)
+        if len(b) != 64:
+            raise ValueError("seed needs 64 bytes")
+        v = int.from_bytes(b, "little") % Q
+        return None if v == 0 else cls(v.to_bytes(32, "little"))
+
+    # PrivateKey::sign / sign_and_bind_pkey (src/signature.rs:62-110): "it is faster to sign with a KeyPair" -- here too:
+    # the public key is recomputed on the GPU first (PublicKey::from(self))
+    def sign(self, message, rng, engine=None):
+        return KeyPair.from_private(self, engine).sign(message, rng, engine)
+
+    def sign_and_bind_pkey(self, message, rng, engine=None):
+        return KeyPair.from_private(self, engine).sign_and_bind_pkey(message, rng, engine)
+
+    def __eq__(self, o):
+        return isinstance(o, PrivateKey) and o.bytes == self.bytes
+
+    def __hash__(self):
+        return hash(self.bytes)
 
 
 class Signature:
@@ -762,6 +796,9 @@ class KeyedSignature:
     def verify(self, message, engine=None):  # src/signature.rs:232-234
         return self.signature.verify(message, self.public_key, engine)
 
+    def __eq__(self, o):
+        return isinstance(o, KeyedSignature) and o.public_key == self.public_key and o.signature == self.signature
+
 
 class KeyPair:
     """KeyPair{private_key, public_key} (src/keypair.rs:48-53)."""
@@ -773,6 +810,22 @@ class KeyPair:
     @classmethod
     def new(cls, rng, engine=None):  # src/keypair.rs:57-65
         return cls.from_private(PrivateKey.new(rng), engine)
+
+    def to_bytes(self):  # src/keypair.rs:73-75: the private key only; the public key is rebuilt when decoding
+        return self.private_key.to_bytes()
+
+    @classmethod
+    def from_bytes(cls, b32, engine=None):  # src/keypair.rs:78-89
+        sk = PrivateKey.from_bytes(b32)
+        return None if sk is None else cls.from_private(sk, engine)
+
+    @classmethod
+    def from_seed(cls, seed64, engine=None):  # src/keypair.rs:92-103
+        sk = PrivateKey.from_seed(seed64)
+        return None if sk is None else cls.from_private(sk, engine)
+
+    def __eq__(self, o):
+        return isinstance(o, KeyPair) and o.private_key == self.private_key and o.public_key == self.public_key
 
     @classmethod
     def from_private(cls, sk, engine=None):  # PublicKey::from(&PrivateKey), src/public.rs:26-32

@@ -29,7 +29,8 @@
 namespace schnorr_sig {
 
 constexpr size_t SCALAR_LENGTH = 32, BASEFIELD_LENGTH = 48, PUBLIC_KEY_LENGTH = 49, SIGNATURE_LENGTH = 81,
-                 KEYED_SIGNATURE_LENGTH = 130, AFFINE_PUBLIC_KEY_LENGTH = 96;  // src/constants.rs:12-30
+                 KEYED_SIGNATURE_LENGTH = 130, AFFINE_PUBLIC_KEY_LENGTH = 96, PRIVATE_KEY_LENGTH = SCALAR_LENGTH,
+                 KEY_PAIR_LENGTH = PRIVATE_KEY_LENGTH;  // src/constants.rs:12-30
 
 enum class SignatureError { InvalidPublicKey = 1, InvalidSignature = 2 };  // src/error.rs:13-18
 inline const char *to_string(SignatureError e) {                           // src/error.rs:20-31
@@ -73,15 +74,82 @@ inline Result status_to_result(int st) {
     throw std::runtime_error(std::string("schnorr_sig_amd: ") + ssa_strerror(st));
 }
 
+struct Signature;
+struct KeyedSignature;
+struct PublicKey;
+
+// a little-endian integer of 64 bytes reduced mod q (Scalar::from_bytes_wide): binary long division, host glue
+inline void reduce_wide_mod_q(const uint8_t wide[64], uint64_t r[4]) {
+    static const uint64_t Q[4] = {0xd443623eaed4accfULL, 0x327aa72330157722ULL, 0x563fbf0f990a37b5ULL, 0x7af2599b3b3f22d0ULL};
+    r[0] = r[1] = r[2] = r[3] = 0;
+    for (int bit = 511; bit >= 0; bit--) {
+        const uint64_t top = r[3] >> 63;
+        r[3] = (r[3] << 1) | (r[2] >> 63);
+        r[2] = (r[2] << 1) | (r[1] >> 63);
+        r[1] = (r[1] << 1) | (r[0] >> 63);
+        r[0] = (r[0] << 1) | ((wide[bit >> 3] >> (bit & 7)) & 1u);
+        bool ge = top != 0;
+        if (!ge) {
+            ge = true;
+            for (int i = 3; i >= 0; i--) {
+                if (r[i] != Q[i]) {
+                    ge = r[i] > Q[i];
+                    break;
+                }
+            }
+        }
+        if (ge) {
+            unsigned __int128 borrow = 0;
+            for (int i = 0; i < 4; i++) {
+                const unsigned __int128 d = (unsigned __int128)r[i] - Q[i] - borrow;
+                r[i] = (uint64_t)d;
+                borrow = (d >> 64) & 1;
+            }
+        }
+    }
+}
+
 struct PrivateKey {  // src/private.rs:25
     std::array<uint8_t, SCALAR_LENGTH> bytes{};
+    bool operator==(const PrivateKey &o) const { return bytes == o.bytes; }
+    std::array<uint8_t, PRIVATE_KEY_LENGTH> to_bytes() const { return bytes; }  // src/private.rs:69-71
+    // PrivateKey::from_bytes, src/private.rs:74-76: nullopt for a non-canonical or zero scalar
+    static std::optional<PrivateKey> from_bytes(const std::array<uint8_t, PRIVATE_KEY_LENGTH> &b) {
+        static const uint64_t Q[4] = {0xd443623eaed4accfULL, 0x327aa72330157722ULL, 0x563fbf0f990a37b5ULL, 0x7af2599b3b3f22d0ULL};
+        uint64_t w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 32; i++) w[i / 8] |= (uint64_t)b[i] << (8 * (i % 8));
+        if ((w[0] | w[1] | w[2] | w[3]) == 0) return std::nullopt;
+        for (int i = 3; i >= 0; i--) {
+            if (w[i] != Q[i]) {
+                if (w[i] > Q[i]) return std::nullopt;
+                PrivateKey k;
+                k.bytes = b;
+                return k;
+            }
+        }
+        return std::nullopt;   // == q
+    }
+    // PrivateKey::from_seed, src/private.rs:79-82
+    static std::optional<PrivateKey> from_seed(const std::array<uint8_t, 64> &seed) {
+        uint64_t r[4];
+        reduce_wide_mod_q(seed.data(), r);
+        if ((r[0] | r[1] | r[2] | r[3]) == 0) return std::nullopt;
+        PrivateKey k;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 8; j++) k.bytes[8 * i + j] = (uint8_t)(r[i] >> (8 * j));
+        return k;
+    }
+    // PrivateKey::sign / sign_and_bind_pkey, src/signature.rs:62-110 ("it is faster to sign with a KeyPair": the public key
+    // is recomputed first, PublicKey::from(self)) -- defined after KeyPair
+    Signature sign(Context &cx, const uint8_t *msg, size_t len, Rng rng) const;
+    KeyedSignature sign_and_bind_pkey(Context &cx, const uint8_t *msg, size_t len, Rng rng) const;
 };
-
-struct Signature;
 
 struct PublicKey {  // src/public.rs:24 -- the in-memory AffinePoint (x, y), canonical LE limbs
     std::array<uint8_t, AFFINE_PUBLIC_KEY_LENGTH> affine{};
     bool is_identity = false;  // AffinePoint::identity() is a valid PublicKey (src/public.rs:95-101)
+    bool operator==(const PublicKey &o) const { return affine == o.affine && is_identity == o.is_identity; }
+    static PublicKey from_private(Context &cx, const PrivateKey &sk);   // impl From<&PrivateKey>, src/public.rs:26-32
     Result verify_signature(Context &cx, const Signature &sig, const uint8_t *msg, size_t len) const;
     // PublicKey::to_bytes, src/public.rs:49-51: the 49-byte compressed wire form
     std::array<uint8_t, PUBLIC_KEY_LENGTH> to_bytes(Context &cx) const {
@@ -159,53 +227,45 @@ struct KeyPair {  // src/keypair.rs:48-53
     // Scalar::random(rng): 64 random bytes reduced mod q (statistical distance from uniform < 2^-256), never 0.
     // (A 32-byte draw reduced mod q, or a masked 254-bit draw, is biased -- fatal for nonces: hidden-number problem.)
     static void random_scalar(Rng &rng, uint8_t out[32]) {
-        static const uint64_t Q[4] = {0xd443623eaed4accfULL, 0x327aa72330157722ULL, 0x563fbf0f990a37b5ULL,
-                                      0x7af2599b3b3f22d0ULL};
         for (;;) {
             uint8_t wide[64];
             rng(wide, sizeof wide);
-            // binary long division of the 512-bit value by q (host glue, 512 shift-subtract steps)
-            uint64_t r[4] = {0, 0, 0, 0};
-            for (int bit = 511; bit >= 0; bit--) {
-                const uint64_t top = r[3] >> 63;
-                r[3] = (r[3] << 1) | (r[2] >> 63);
-                r[2] = (r[2] << 1) | (r[1] >> 63);
-                r[1] = (r[1] << 1) | (r[0] >> 63);
-                r[0] = (r[0] << 1) | ((wide[bit >> 3] >> (bit & 7)) & 1u);
-                bool ge = top != 0;
-                if (!ge) {
-                    ge = true;
-                    for (int i = 3; i >= 0; i--) {
-                        if (r[i] != Q[i]) {
-                            ge = r[i] > Q[i];
-                            break;
-                        }
-                    }
-                }
-                if (ge) {
-                    unsigned __int128 borrow = 0;
-                    for (int i = 0; i < 4; i++) {
-                        const unsigned __int128 d = (unsigned __int128)r[i] - Q[i] - borrow;
-                        r[i] = (uint64_t)d;
-                        borrow = (d >> 64) & 1;
-                    }
-                }
-            }
+            uint64_t r[4];
+            reduce_wide_mod_q(wide, r);
             if ((r[0] | r[1] | r[2] | r[3]) == 0) continue;   // PrivateKey::new rejects 0 (src/private.rs:49-57)
             for (int i = 0; i < 4; i++)
                 for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(r[i] >> (8 * k));
             return;
         }
     }
-    // KeyPair::new, src/keypair.rs:57-65
-    static KeyPair create(Context &cx, Rng rng) {
+    bool operator==(const KeyPair &o) const { return private_key == o.private_key && public_key == o.public_key; }
+    // impl From<&PrivateKey> for KeyPair, src/keypair.rs:21-32: the public key is [sk]G, computed by the constant-time signer
+    static KeyPair from_private(Context &cx, const PrivateKey &sk) {
         KeyPair kp;
-        random_scalar(rng, kp.private_key.bytes.data());
+        kp.private_key = sk;
         uint8_t sig[SIGNATURE_LENGTH], msg = 0;
-        int rc = ssa_keygen_sign_many_ex(cx.get(), kp.private_key.bytes.data(), kp.private_key.bytes.data(), &msg,
-                                         nullptr, 1, 1, 1, SSA_FLAG_SIGN_CT, kp.public_key.affine.data(), sig);
+        int rc = ssa_keygen_sign_many_ex(cx.get(), sk.bytes.data(), sk.bytes.data(), &msg, nullptr, 1, 1, 1, SSA_FLAG_SIGN_CT,
+                                         kp.public_key.affine.data(), sig);
         if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many_ex: ") + ssa_strerror(rc));
         return kp;
+    }
+    // KeyPair::to_bytes / from_bytes / from_seed, src/keypair.rs:73-103: the private key only, the public key is rebuilt
+    std::array<uint8_t, KEY_PAIR_LENGTH> to_bytes() const { return private_key.to_bytes(); }
+    static std::optional<KeyPair> from_bytes(Context &cx, const std::array<uint8_t, KEY_PAIR_LENGTH> &b) {
+        const auto sk = PrivateKey::from_bytes(b);
+        if (!sk) return std::nullopt;
+        return from_private(cx, *sk);
+    }
+    static std::optional<KeyPair> from_seed(Context &cx, const std::array<uint8_t, 64> &seed) {
+        const auto sk = PrivateKey::from_seed(seed);
+        if (!sk) return std::nullopt;
+        return from_private(cx, *sk);
+    }
+    // KeyPair::new, src/keypair.rs:57-65
+    static KeyPair create(Context &cx, Rng rng) {
+        PrivateKey sk;
+        random_scalar(rng, sk.bytes.data());
+        return from_private(cx, sk);
     }
     // KeyPair::sign, src/signature.rs:114-129 (constant-time in the key and the nonce, like the reference)
     Signature sign(Context &cx, const uint8_t *msg, size_t len, Rng rng) const {
@@ -235,6 +295,14 @@ struct KeyPair {  // src/keypair.rs:48-53
         return sig.verify(cx, msg, len, public_key);  // src/signature.rs:159-165
     }
 };
+
+inline PublicKey PublicKey::from_private(Context &cx, const PrivateKey &sk) { return KeyPair::from_private(cx, sk).public_key; }
+inline Signature PrivateKey::sign(Context &cx, const uint8_t *msg, size_t len, Rng rng) const {
+    return KeyPair::from_private(cx, *this).sign(cx, msg, len, rng);
+}
+inline KeyedSignature PrivateKey::sign_and_bind_pkey(Context &cx, const uint8_t *msg, size_t len, Rng rng) const {
+    return KeyPair::from_private(cx, *this).sign_and_bind_pkey(cx, msg, len, rng);
+}
 
 // Many signatures by few signers (validator sets; the reference's own batch test reuses keys, src/batch.rs:152-175):
 // the key checks of Signature::verify -- canonical limbs, on the curve, subgroup check (src/signature.rs:182-184) --

@@ -48,6 +48,31 @@ int main() {
     r = e0.verify(cx, message, sizeof message, kp.public_key);
     CHECK(r && *r == SignatureError::InvalidSignature);
 
+    // tests/schnorr.rs:27-56,59-146: a bare private key signs, the key types' codecs round-trip
+    {
+        PrivateKey sk = kp.private_key;
+        CHECK(PublicKey::from_private(cx, sk) == kp.public_key);
+        CHECK(KeyPair::from_private(cx, sk) == kp);
+        const auto kb = kp.to_bytes();
+        CHECK(kb.size() == KEY_PAIR_LENGTH);
+        const auto kp2 = KeyPair::from_bytes(cx, kb);
+        CHECK(kp2 && *kp2 == kp);
+        const auto sk2 = PrivateKey::from_bytes(sk.to_bytes());
+        CHECK(sk2 && *sk2 == sk);
+        std::array<uint8_t, 32> zero{}, ones;
+        ones.fill(0xff);
+        CHECK(!PrivateKey::from_bytes(zero) && !PrivateKey::from_bytes(ones));
+        std::array<uint8_t, 64> seed;
+        rng(seed.data(), seed.size());
+        const auto ks1 = KeyPair::from_seed(cx, seed);
+        const auto ss1 = PrivateKey::from_seed(seed);
+        CHECK(ks1 && ss1 && ks1->private_key == *ss1);
+        Signature s1 = sk.sign(cx, message, sizeof message, rng);
+        CHECK(!s1.verify(cx, message, sizeof message, kp.public_key));
+        KeyedSignature k1 = sk.sign_and_bind_pkey(cx, message, sizeof message, rng);
+        CHECK(k1.public_key == kp.public_key && !k1.verify(cx, message, sizeof message));
+    }
+
     // wire forms of the signing side (src/public.rs:49-56, src/signature.rs:132-156,232-271)
     {
         const auto pkb = kp.public_key.to_bytes(cx);

@@ -468,3 +468,61 @@ def test_narrow_coefficients_are_the_value_their_signed_digits_represent(engine,
                                        verdict.data_ptr())
         engine.sync()
         assert int(verdict.item()) == 2, lane
+
+
+# ---------------------------------------------------------------- the reference's own integration tests, name for name
+def test_reference_integration_tests_through_the_mirror(engine):
+    """tests/schnorr.rs of the reference through the Python mirror of its API (same names, same argument meaning, Option ->
+    None, Result -> SignatureError): key_creation_and_conversion (:27-56), signing_and_verification_of_single_signature
+    (:59-146) and batch_verification_of_three_signatures (:149-182), serde blocks aside."""
+    import os as _os
+    import schnorr_sig_amd as ssa
+    rng = lambda k: _os.urandom(k)
+
+    # key_creation_and_conversion
+    sk = ssa.PrivateKey.new(rng)
+    pk = ssa.PublicKey.from_private(sk, engine)
+    kp = ssa.KeyPair.from_private(sk, engine)
+    assert kp.private_key == sk and kp.public_key == pk
+    assert ssa.KeyPair.from_bytes(kp.to_bytes(), engine) == kp
+    seed = _os.urandom(64)
+    assert ssa.KeyPair.from_seed(seed, engine).private_key == ssa.PrivateKey.from_seed(seed)
+    assert ssa.PrivateKey.from_bytes(b"\0" * 32) is None and ssa.PrivateKey.from_bytes(b"\xff" * 32) is None
+
+    # signing_and_verification_of_single_signature, first block: a bare private key signs
+    message = b"A random message"
+    signature = sk.sign(message, rng, engine)
+    assert signature.verify(message, pk, engine) is None
+    signature_bytes = signature.to_bytes()
+    assert len(signature_bytes) == ssa.SIGNATURE_LENGTH
+    assert signature == ssa.Signature.from_bytes(signature_bytes)
+    keyed_signature = sk.sign_and_bind_pkey(message, rng, engine)
+    assert keyed_signature.verify(message, engine) is None
+    signature_bytes = keyed_signature.to_bytes(engine)
+    assert len(signature_bytes) == ssa.KEYED_SIGNATURE_LENGTH
+    assert keyed_signature == ssa.KeyedSignature.from_bytes(signature_bytes, engine)
+
+    # second block: a key pair signs, every verifier agrees, every codec round-trips
+    signer = ssa.KeyPair.new(rng, engine)
+    signature = signer.sign(message, rng, engine)
+    assert signature.verify(message, signer.public_key, engine) is None
+    assert signer.verify_signature(signature, message) is None
+    assert signer.public_key.verify_signature(signature, message) is None
+    assert signer.sign_and_bind_pkey(message, rng, engine).verify(message, engine) is None
+    private_key_bytes, public_key_bytes, keypair_bytes = signer.private_key.to_bytes(), signer.public_key.to_bytes(engine), signer.to_bytes()
+    assert len(private_key_bytes) == ssa.PRIVATE_KEY_LENGTH and signer.private_key == ssa.PrivateKey.from_bytes(private_key_bytes)
+    assert len(public_key_bytes) == ssa.PUBLIC_KEY_LENGTH and signer.public_key == ssa.PublicKey.from_bytes(public_key_bytes, engine)
+    assert len(keypair_bytes) == ssa.KEY_PAIR_LENGTH and signer == ssa.KeyPair.from_bytes(keypair_bytes, engine)
+
+    # batch_verification_of_three_signatures: signer 3 IS signer 1, the messages have three different lengths
+    signer_1, signer_2 = ssa.KeyPair.new(rng, engine), ssa.KeyPair.new(rng, engine)
+    signer_3 = signer_1
+    messages = [b"A random message to sign", b"Another message to sign!", b"And once again another message from the others!!"]
+    signers = [signer_1, signer_2, signer_3]
+    signatures = [sg.sign(m, rng, engine) for sg, m in zip(signers, messages)]
+    public_keys = [sg.public_key for sg in signers]
+    for sig, m, k in zip(signatures, messages, public_keys):
+        assert sig.verify(m, k, engine) is None
+    assert ssa.verify_batch(signatures, public_keys, messages, rng, engine) is None
+    assert ssa.verify_batch(signatures, public_keys, messages, rng, engine, msm=True) is None       # the reference's own algorithm
+
