@@ -76,6 +76,29 @@ def test_verify_batch_length_mismatch_panics_like_the_reference():
     assert ssa.verify_batch([], [], []) is None      # empty batch is Ok (src/batch.rs)
 
 
+def test_private_key_codecs_like_the_reference():
+    """src/private.rs:118-185 (test_encoding, test_from_seed) on the mirror's host-side scalar codecs: known encodings,
+    round trips, the invalid encodings the reference lists (zero, all ones, top byte 127), a seed whose upper half is zero"""
+    import schnorr_sig_amd as ssa
+    one = bytes([1] + [0] * 31)
+    assert ssa.PrivateKey(one).to_bytes() == one                       # from_scalar(Scalar::one()).to_bytes()
+    rng = lambda k: os.urandom(k)
+    for _ in range(100):
+        key = ssa.PrivateKey.new(rng)
+        b = key.to_bytes()
+        assert len(b) == ssa.PRIVATE_KEY_LENGTH and key == ssa.PrivateKey.from_bytes(b)
+        assert key == ssa.PrivateKey.from_seed(b + bytes(32))         # seed[0..32] = the key's bytes (:164-176)
+    assert ssa.PrivateKey.from_bytes(bytes(32)) is None
+    assert ssa.PrivateKey.from_bytes(b"\xff" * 32) is None
+    assert ssa.PrivateKey.from_bytes(ssa.PrivateKey.new(rng).to_bytes()[:31] + bytes([127])) is None   # :203-204
+    assert ssa.PrivateKey.from_seed(bytes(64)) is None
+    q = ssa.Q
+    assert ssa.PrivateKey.from_bytes(q.to_bytes(32, "little")) is None
+    assert ssa.PrivateKey.from_bytes((q - 1).to_bytes(32, "little")).to_bytes() == (q - 1).to_bytes(32, "little")
+    wide = int.from_bytes(os.urandom(64), "little")
+    assert int.from_bytes(ssa.PrivateKey.from_seed(wide.to_bytes(64, "little")).to_bytes(), "little") == wide % q
+
+
 def test_pack_messages():
     import schnorr_sig_amd as ssa
     flat, off = ssa.pack_messages([b"ab", b"", b"cde"])
