@@ -610,6 +610,14 @@ def main():
                                  "meaning": "what ssa_verify_batch sets: no subgroup check, byte 48 of the signature "
                                             "honoured (src/batch.rs:104); the CPU leg runs the same flags"},
                        "parallelism": "shard%d" % world, "corrupt_fraction": args.corrupt,
+                       # what the context holds on the device (ssa_ctx_info, read AFTER the run): the comb for G is a
+                       # speed-for-memory choice of the context (ssa_ctx_create_ex), the workspaces are per slice
+                       "device_memory": (lambda i: {"gtab_window_bits": i["gtab_bits"], "gtab_windows": i["gtab_windows"],
+                                                    "gtab_bytes": i["gtab_bytes"], "workspace_bytes": i["workspace_bytes"],
+                                                    "lane_slice": i["lane_slice"], "msm_slice": i["msm_slice"],
+                                                    "hbm_budget_bytes": i["hbm_budget_bytes"],
+                                                    "slices_on_two_streams": i["two_streams"]})(eng.info())
+                       if hasattr(eng, "info") else None,
                        "backend": rk.backend if rk.dist is not None else None,
                        "process_group": ("forced one-rank group (RCCL rehearsal)" if rk.forced else "torchrun ranks")
                        if rk.dist is not None else None},

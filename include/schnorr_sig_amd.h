@@ -22,6 +22,7 @@
  *                                                           src/signature.rs:114-129
  *   ssa_keygen_sign_many_ex <- the same, constant-time (SSA_FLAG_SIGN_CT) and / or as KeyedSignature records
  *                              (sign_and_bind_pkey + KeyedSignature::to_bytes, src/signature.rs:132-156,237-245)
+ *   ssa_pubkey_many         <- PublicKey::from(&PrivateKey) src/public.rs:26-32
  *   ssa_compress_many       <- PublicKey::to_bytes          src/public.rs:49-51
  *   status codes            <- SignatureError               src/error.rs:13-18
  *   record sizes            <- src/constants.rs:12-30
@@ -71,8 +72,12 @@ extern "C" {
 #define SSA_ERR_NO_DEVICE (-4)
 
 /* flags */
-#define SSA_MAX_BATCH ((size_t)1 << 30)   /* signatures per call; larger n returns SSA_ERR_ARG.  The per-lane workspaces are
-                                             sized for slices of 2^20 lanes (2.1 GB; SSA_LANE_SLICE), not for n */
+#define SSA_MAX_BATCH ((size_t)1 << 30)   /* signatures per call; larger n returns SSA_ERR_ARG.  Device memory does not grow
+                                             with n, for device-pointer AND host-buffer entry points: workspaces and
+                                             staging are sized for slices of 2^20 lanes (4.4 GB of tables + 0.3 GB of
+                                             staging per slice in flight, at most two; SSA_LANE_SLICE), resp. 2^23
+                                             signatures of the MSM form (SSA_MSM_SLICE); only the slice in flight is
+                                             pinned */
 #define SSA_FLAG_FORCE_LANE 2u    /* always the throughput kernels (one signature per lane) */
 #define SSA_FLAG_FORCE_COOP 4u    /* always the low-latency kernel (one wave per signature) */
 #define SSA_FLAG_CHECK_TORSION 1u /* Signature::verify semantics (src/signature.rs:182-184);
@@ -93,10 +98,28 @@ typedef struct ssa_ctx ssa_ctx;
  * upstream's (they live in un-vendored crates; DESIGN.md "parity unpinned"): such a context rejects every genuine
  * toposware signature and ssa_ctx_uses_default_params() returns 1 for it.  tools/blob_from_upstream.py builds the
  * blob from upstream's constants.  The generator is validated on the device (on the curve, [q]G == O):
- * SSA_ERR_PARAMS otherwise.  Device memory: the fixed-base comb table of the generator is 17.7 GB -- one per device and
- * generator, shared by all the contexts of the process --, the per-lane workspaces grow to 4.4 GB with the first large
- * batch (slices of 2^20 lanes, whatever the batch size). */
+ * SSA_ERR_PARAMS otherwise.  Device memory: the fixed-base comb table of the generator (the reference's const
+ * BASEPOINT_TABLE, src/signature.rs:20,116, src/batch.rs:98-100) is sized by the context -- see ssa_ctx_create_ex --,
+ * one per device, generator and geometry, shared by all the contexts of the process; the per-lane workspaces grow to
+ * 4.4 GB with the first large batch (slices of 2^20 lanes, whatever the batch size), twice that once a call of more than
+ * one slice has used the second internal stream. */
 int ssa_ctx_create(ssa_ctx **out, int device, const void *params, size_t params_len);
+/* The same with the speed-for-memory trade chosen by the caller.
+ *   gtab_bits         window width of the comb for G: 24 (11 windows, 17.7 GB: [e]G = 11 additions), 22 (12, 4.8 GB),
+ *                     20 (13, 1.3 GB) or 16 (16, 100 MB; ssa_k_verify +1.9 %); 0 = the widest whose table fits the budget
+ *                     (environment: SSA_GTAB_BITS).  Results are identical for every width.
+ *   hbm_budget_bytes  what the tables that only buy speed may take on the device -- the comb for G, the per-key combs of
+ *                     an SSA_KEYSET_AUTO key set; 0 = a tenth of the memory that is free when the context is created
+ *                     (environment: SSA_HBM_BUDGET_MB).
+ * An allocation that fails is not an error while a smaller table exists: the context falls back width by width down
+ * to the 100 MB comb (ssa_ctx_info says what it got). */
+int ssa_ctx_create_ex(ssa_ctx **out, int device, const void *params, size_t params_len, uint32_t gtab_bits,
+                      uint64_t hbm_budget_bytes);
+/* What the context holds on the device: out[0] window bits and out[1] windows of the comb for G, out[2] its bytes,
+ * out[3] bytes of this context's workspaces and staging buffers as reserved so far, out[4] lanes per slice of the
+ * per-lane kernels, out[5] signatures per slice of the MSM form, out[6] the HBM budget, out[7] 1 when calls of more than
+ * one slice alternate their slices between two internal streams (SSA_TWO_STREAMS=0 turns that off). */
+int ssa_ctx_info(const ssa_ctx *ctx, uint64_t out[8]);
 /* 1 when the context was created from the built-in blob (parity with upstream unpinned), 0 for a caller-supplied one */
 int ssa_ctx_uses_default_params(const ssa_ctx *ctx);
 void ssa_ctx_destroy(ssa_ctx *ctx);
@@ -199,6 +222,14 @@ int ssa_keygen_sign_many_ex(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *non
                             const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n, uint32_t flags,
                             uint8_t *pks_out, uint8_t *sigs_out);
 
+/* PublicKey::from(&PrivateKey) (src/public.rs:26-32; KeyPair::from_bytes / from_seed re-derive the key the same way,
+ * src/keypair.rs:73-103): pks_out[i] = [sks[i]]G as 96-byte affine points -- ONE constant-time base multiplication per
+ * key (the signer's table and window code) and nothing else derived from the secret: no nonce, no response scalar.
+ * The host form checks the scalars (canonical, non-zero: SSA_ERR_ARG otherwise) in time independent of their values and
+ * wipes its device copy before it returns; the _device form computes [sk mod q]G for any 32 bytes, through the
+ * variable-time fallback when sk reduces to 0. */
+int ssa_pubkey_many(ssa_ctx *ctx, const uint8_t *sks, size_t n, uint8_t *pks_out);
+
 /* PublicKey::to_bytes (AffinePoint::to_compressed, src/public.rs:49-51): n x 96-byte affine points -> n x 49 bytes
  * x || flag byte (bit 7: the identity, [0; 48] || 0x80, src/public.rs:95-101 -- marked by pk_inf[i] != 0, optional; bit 6:
  * the sort flag of y).  status_out (optional): 0, or SSA_MALFORMED for a limb that is not canonical. */
@@ -238,10 +269,13 @@ int ssa_keygen_sign_many_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_
                                 uint8_t *d_sigs_out);
 int ssa_decompress_many_device(ssa_ctx *ctx, const uint8_t *d_compressed, size_t n, uint8_t *d_pks_out,
                                uint8_t *d_pk_inf_out, uint8_t *d_status_out);
-/* (cannot report errors per lane: scalars are reduced mod q; d_pks_out may be NULL with SSA_FLAG_SIGN_KEYED) */
+/* (cannot report errors per lane: scalars are reduced mod q; d_pks_out may be NULL with SSA_FLAG_SIGN_KEYED.
+ *  PRECONDITION of SSA_FLAG_SIGN_CT on device buffers: every sk and nonce is canonical and non-zero -- what the host form
+ *  checks; a scalar that reduces to 0 is still signed correctly, but by the variable-time fallback) */
 int ssa_keygen_sign_many_ex_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces, const uint8_t *d_msgs,
                                    const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
                                    uint32_t flags, uint8_t *d_pks_out, uint8_t *d_sigs_out);
+int ssa_pubkey_many_device(ssa_ctx *ctx, const uint8_t *d_sks, size_t n, uint8_t *d_pks_out);
 int ssa_compress_many_device(ssa_ctx *ctx, const uint8_t *d_pks, const uint8_t *d_pk_inf, size_t n, uint8_t *d_out,
                              uint8_t *d_status_out);
 /* coeff_bytes in 1..32: little-endian coefficient width (d_coeffs == NULL: the library draws 128-bit
@@ -344,7 +378,7 @@ int ssa_msm_combine(ssa_ctx *ctx, const uint64_t *parts24, size_t k);
  * Bumped whenever an exported signature changes (round 2 inserted pk_inf into the batch entry points under the same
  * symbol names: a shim built against the older header would still link and pass msgs as pk_inf).  A binding checks
  * ssa_abi_version() == SSA_ABI_VERSION at load; the Python and C++ mirrors do. */
-#define SSA_ABI_VERSION 4
+#define SSA_ABI_VERSION 5
 int ssa_abi_version(void);
 
 /* ---- arithmetic probes (unit parity with the oracle; not part of the reference API) --- */

@@ -120,6 +120,10 @@ def _load():
     vp, sz, u32, u64p, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64), C.c_int
     sigs = {
         "ssa_ctx_create": (i32, [C.POINTER(vp), i32, vp, sz]),
+        "ssa_ctx_create_ex": (i32, [C.POINTER(vp), i32, vp, sz, u32, C.c_uint64]),
+        "ssa_ctx_info": (i32, [vp, u64p]),
+        "ssa_pubkey_many": (i32, [vp, vp, sz, vp]),
+        "ssa_pubkey_many_device": (i32, [vp, vp, sz, vp]),
         "ssa_ctx_destroy": (None, [vp]),
         "ssa_strerror": (C.c_char_p, [i32]),
         "ssa_default_params": (vp, []),
@@ -182,7 +186,7 @@ def _load():
     return lib, list(sigs)
 
 
-ABI_VERSION = 4        # SSA_ABI_VERSION of include/schnorr_sig_amd.h
+ABI_VERSION = 5        # SSA_ABI_VERSION of include/schnorr_sig_amd.h
 MSM_PARTIAL_WORDS = 24
 MSM_RECORD_MAGIC = 0x5353415245430004     # SSA_MSM_RECORD_MAGIC: word 23 of every shard record
 _lib, ABI_SYMBOLS = _load()
@@ -217,14 +221,24 @@ def pack_messages(messages):
 class Engine:
     """One ssa_ctx: a device, a stream, the comb table for G and the workspaces."""
 
-    def __init__(self, device=0, params=None):
+    def __init__(self, device=0, params=None, gtab_bits=0, hbm_budget_bytes=0):
+        """gtab_bits: window width of the comb for G (16 / 20 / 22 / 24; 0 = the widest whose table fits the budget);
+        hbm_budget_bytes: device memory the speed-for-memory tables may take (0 = a tenth of what is free)."""
         self._ctx = C.c_void_p()
         blob = None
         if params is not None:
             blob = (C.c_uint8 * len(params)).from_buffer_copy(bytes(params))
-        _check(_lib.ssa_ctx_create(C.byref(self._ctx), int(device), blob, len(params) if params else 0),
-               "ssa_ctx_create")
+        _check(_lib.ssa_ctx_create_ex(C.byref(self._ctx), int(device), blob, len(params) if params else 0,
+                                      int(gtab_bits), int(hbm_budget_bytes)), "ssa_ctx_create_ex")
         self.device = int(device)
+
+    def info(self):
+        """what the context holds on the device (ssa_ctx_info)"""
+        out = (C.c_uint64 * 8)()
+        _check(_lib.ssa_ctx_info(self._ctx, out), "ssa_ctx_info")
+        return {"gtab_bits": int(out[0]), "gtab_windows": int(out[1]), "gtab_bytes": int(out[2]),
+                "workspace_bytes": int(out[3]), "lane_slice": int(out[4]), "msm_slice": int(out[5]),
+                "hbm_budget_bytes": int(out[6]), "two_streams": bool(out[7])}
 
     def close(self):
         if self._ctx:
@@ -385,6 +399,18 @@ class Engine:
                                             flags, _ptr(pks), _ptr(sigs)), "ssa_keygen_sign_many_ex")
         return pks, sigs
 
+    def pubkey_many(self, sks):
+        """PublicKey::from(&PrivateKey) for n canonical non-zero scalars -> uint8[n, 96]: one constant-time base
+        multiplication per key, nothing else derived from the secret (ssa_pubkey_many)"""
+        sks = _np_u8(sks, 32)
+        n = sks.shape[0]
+        pks = np.zeros((n, 96), dtype=np.uint8)
+        _check(_lib.ssa_pubkey_many(self._ctx, _ptr(sks), n, _ptr(pks)), "ssa_pubkey_many")
+        return pks
+
+    def pubkey_many_device(self, d_sks, n, d_pks):
+        _check(_lib.ssa_pubkey_many_device(self._ctx, C.c_void_p(d_sks), n, C.c_void_p(d_pks)), "ssa_pubkey_many_device")
+
     def compress_many(self, pks, pk_inf=None):
         """PublicKey::to_bytes for n affine keys -> (uint8[n, 49], status uint8[n])"""
         pks = _np_u8(pks, 96)
@@ -420,8 +446,9 @@ class Engine:
 
     # ---- keyed context (many signatures by few signers) ---------------------------------
     def keyset_create(self, pks, pk_inf=None, kind="auto"):
-        """-> KeySet: subgroup check and tables done once per key.  kind: "auto", "comb" (768 KB
-        per key, no doublings at verification time) or "ladder" (2 KB per key)"""
+        """-> KeySet: subgroup check and tables done once per key.  kind: "auto" (combs while they fit the context's HBM
+        budget, else -- or when their allocation fails -- the ladder tables), "comb" (100 MB per key, no doublings at
+        verification time) or "ladder" (4 KB per key)"""
         pks = _np_u8(pks, 96)
         inf = _np_u8(pk_inf) if pk_inf is not None else None
         ks = C.c_void_p()
@@ -830,8 +857,7 @@ class KeyPair:
     @classmethod
     def from_private(cls, sk, engine=None):  # PublicKey::from(&PrivateKey), src/public.rs:26-32
         eng = engine or default_engine()
-        pks, _ = eng.keygen_sign_many(np.frombuffer(sk.bytes, np.uint8), np.frombuffer(sk.bytes, np.uint8),
-                                      np.zeros((1, 1), np.uint8), constant_time=True)
+        pks = eng.pubkey_many(np.frombuffer(sk.bytes, np.uint8))     # [sk]G and nothing else (no nonce, no response)
         return cls(sk, PublicKey(pks[0].tobytes()))
 
     def _nonce(self, rng):  # Scalar::random: 64 random bytes mod q, never 0

@@ -33,7 +33,7 @@ extern "C" int ssa_abi_version(void) { return SSA_ABI_VERSION; }
 struct ssa_keyset {
     ssa_ctx *ctx = nullptr;   // nullptr: the context is gone, the device memory went with it
     size_t m = 0;
-    bool comb = false;      // per-key comb tables (768 KB per key) instead of the ladder's eight multiples
+    bool comb = false;      // per-key comb tables (16 x 65536 rows = 100 MB per key) instead of the ladder's 16 multiples
     DevBuf tab, status, pks, ktab;
     void release_all() {
         tab.release();
@@ -43,12 +43,13 @@ struct ssa_keyset {
     }
 };
 
-// The comb table depends on the device and the generator only, and it is 4.8 GB: contexts of one process share it
-// (reference-counted; ssa_multi_create with several contexts per device, the tests' many engines, a binding that makes
-// a context per thread).  Built at the first acquisition on the acquiring context's stream, synchronously, under the
-// registry's lock; read-only afterwards.
+// The comb table depends on the device, the generator and its geometry only, and it is up to 17.7 GB: contexts of one
+// process share it (reference-counted; ssa_multi_create with several contexts per device, the tests' many engines, a
+// binding that makes a context per thread).  Built at the first acquisition on the acquiring context's stream,
+// synchronously, under the registry's lock; read-only afterwards.
 struct SharedGtab {
     int device = 0;
+    u32 bits = 0;
     u64 gen[12] = {};
     u64 *d_gtab = nullptr;
     int refs = 0;
@@ -56,7 +57,10 @@ struct SharedGtab {
 static std::mutex g_gtab_mu;
 static std::vector<SharedGtab *> g_gtabs;
 
-static SharedGtab *gtab_acquire(ssa_ctx *ctx, const DevParams &hp) {
+static inline size_t gtab_bytes(u32 bits) { return gtab_entries(bits) * 12 * sizeof(u64); }
+
+// the table of `bits`-bit windows for this generator on this device: an existing one, or a new one (nullptr: no memory)
+static SharedGtab *gtab_acquire(ssa_ctx *ctx, const DevParams &hp, u32 bits) {
     std::lock_guard<std::mutex> lock(g_gtab_mu);
     u64 gen[12];
     for (int i = 0; i < 6; i++) {
@@ -64,23 +68,27 @@ static SharedGtab *gtab_acquire(ssa_ctx *ctx, const DevParams &hp) {
         gen[6 + i] = hp.gen_y[i];
     }
     for (SharedGtab *g : g_gtabs)
-        if (g->device == ctx->device && std::memcmp(g->gen, gen, sizeof gen) == 0) {
+        if (g->device == ctx->device && g->bits == bits && std::memcmp(g->gen, gen, sizeof gen) == 0) {
             g->refs++;
             return g;
         }
     SharedGtab *g = new SharedGtab();
     g->device = ctx->device;
+    g->bits = bits;
     std::memcpy(g->gen, gen, sizeof gen);
-    // 49 152 base entries by double-and-add, then one affine addition per entry (ssa_kernels.hpp)
+    // base entries by double-and-add (90 112 of them for 24-bit windows), then one affine addition per entry
+    // (ssa_kernels.hpp)
     void *gbase = nullptr;
-    bool ok = hipMalloc((void **)&g->d_gtab, GTAB_ENTRIES * 12 * sizeof(u64)) == hipSuccess &&
-              hipMalloc(&gbase, GBASE_ENTRIES * 12 * sizeof(u64)) == hipSuccess;
+    bool ok = hipMalloc((void **)&g->d_gtab, gtab_bytes(bits)) == hipSuccess &&
+              hipMalloc(&gbase, gbase_entries(bits) * 12 * sizeof(u64)) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(ssa_k_gbase, dim3(grid_for(GBASE_ENTRIES, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
-                           (u64 *)gbase);
-        hipLaunchKernelGGL(ssa_k_gtable, dim3(grid_for(GTAB_ENTRIES / 8, 256)), dim3(256), 0, ctx->stream,
-                           (const u64 *)gbase, g->d_gtab);
+        hipLaunchKernelGGL(ssa_k_gbase, dim3(grid_for(gbase_entries(bits), 256)), dim3(256), 0, ctx->stream, ctx->d_params,
+                           (u64 *)gbase, bits);
+        hipLaunchKernelGGL(ssa_k_gtable, dim3(grid_for(gtab_entries(bits) / 8, 256)), dim3(256), 0, ctx->stream,
+                           (const u64 *)gbase, g->d_gtab, bits);
         ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    } else {
+        (void)hipGetLastError();      // an allocation that did not fit is not a sticky error: the caller tries a smaller table
     }
     if (gbase) (void)hipFree(gbase);
     if (!ok) {
@@ -123,8 +131,19 @@ static int validate_params(const DevParams &p) {
 }
 
 extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, size_t params_len) {
+    return ssa_ctx_create_ex(out, device, params, params_len, 0u, 0ull);
+}
+
+// gtab_bits: window width of the comb for G (16, 20, 22 or 24; 0 = the widest whose table fits the budget; the
+// environment's SSA_GTAB_BITS overrides 0).  hbm_budget_bytes: what the library may spend on tables that are a pure
+// speed-for-memory trade (the comb for G, per-key combs of a key set); 0 = a tenth of the device memory that is free
+// when the context is created (SSA_HBM_BUDGET_MB overrides 0).  An allocation that fails falls back to the next
+// smaller table instead of failing the context: the 16-bit comb (100 MB) is the floor.
+extern "C" int ssa_ctx_create_ex(ssa_ctx **out, int device, const void *params, size_t params_len, uint32_t gtab_bits,
+                                 uint64_t hbm_budget_bytes) {
     if (!out) return SSA_ERR_ARG;
     *out = nullptr;
+    if (gtab_bits != 0 && gtab_bits != 16 && gtab_bits != 20 && gtab_bits != 22 && gtab_bits != 24) return SSA_ERR_ARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return SSA_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return SSA_ERR_ARG;
@@ -169,6 +188,7 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         const int v = std::atoi(tg);
         if (v >= 2 && v <= 64) ctx->msm_tree_group = (unsigned)v;
     }
+    if (const char *ts = std::getenv("SSA_TWO_STREAMS")) ctx->two_streams = std::atoi(ts) != 0;
     if (const char *pc = std::getenv("SSA_PIPELINE_CHUNKS")) {
         const int v = std::atoi(pc);
         if (v >= 1 && v <= 8) ctx->pipeline_chunks = (unsigned)v;
@@ -203,13 +223,38 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
-    // the comb table of this generator on this device: shared by every context that asks for it (4.8 GB)
-    ctx->gtab_share = gtab_acquire(ctx, hp);
+    ctx->h_params = hp;
+    // HBM budget of the speed-for-memory tables, and the comb geometry it allows
+    if (hbm_budget_bytes == 0) {
+        if (const char *mb = std::getenv("SSA_HBM_BUDGET_MB")) hbm_budget_bytes = std::strtoull(mb, nullptr, 10) << 20;
+    }
+    if (hbm_budget_bytes == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        hbm_budget_bytes = free_b / 10;
+    }
+    ctx->hbm_budget = hbm_budget_bytes;
+    if (gtab_bits == 0) {
+        if (const char *gb = std::getenv("SSA_GTAB_BITS")) {
+            const int v = std::atoi(gb);
+            if (v == 16 || v == 20 || v == 22 || v == 24) gtab_bits = (uint32_t)v;
+        }
+    }
+    // the comb table of this generator on this device: shared by every context that asks for the same geometry.
+    // Forced width: that one first; automatic: the widest within the budget.  Either way a failed allocation moves on
+    // to the next smaller table.
+    static const u32 k_widths[4] = {24, 22, 20, 16};
+    for (u32 wbits : k_widths) {
+        if (gtab_bits ? wbits > gtab_bits : (wbits > 16 && gtab_bytes(wbits) > hbm_budget_bytes)) continue;
+        ctx->gtab_share = gtab_acquire(ctx, hp, wbits);
+        if (ctx->gtab_share) break;
+    }
     if (!ctx->gtab_share || ctx->ws_fail.reserve(64)) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
     }
     ctx->d_gtab = ctx->gtab_share->d_gtab;
+    ctx->gtab_bits = ctx->gtab_share->bits;
     // the generator must be a point of the prime-order subgroup: on the curve, [q]G == O (through the comb table
     // just built), G != O -- otherwise every verification would run on some other curve or a small subgroup
     unsigned gen_ok = 0;
@@ -229,10 +274,42 @@ extern "C" int ssa_ctx_create(ssa_ctx **out, int device, const void *params, siz
     return 0;
 }
 
+// The second set of streams and workspaces of a context (calls of more than one slice alternate between the two, so
+// that the tail of one slice's kernels -- the last wave of every SIMD runs alone, the XCDs finish 1.5-4 % apart: 0.9 ms
+// of a 26.6 ms ssa_k_verify, 0.35 of an 8 ms ssa_k_hash -- is filled by the next slice's): a context of its own on the
+// same device, blob and comb table (the registry hands the table out again: no second copy), owned by `ctx`.
+ssa_ctx *ssa_internal_twin(ssa_ctx *ctx) {
+    if (ctx->is_twin || !ctx->two_streams) return nullptr;
+    if (!ctx->twin) {
+        DevParams hp = ctx->h_params;
+        hp.flags = 0;
+        ssa_ctx *t = nullptr;
+        if (ssa_ctx_create_ex(&t, ctx->device, &hp, sizeof hp, ctx->gtab_bits, ctx->hbm_budget) != 0) {
+            ctx->two_streams = false;          // no memory for a second workspace: one stream, as before
+            return nullptr;
+        }
+        t->is_twin = true;
+        t->default_params = ctx->default_params;
+        t->lane_slice = ctx->lane_slice;
+        t->coop_max_n = ctx->coop_max_n;
+        t->coop_max_n_torsion = ctx->coop_max_n_torsion;
+        t->pipeline_chunks = ctx->pipeline_chunks;
+        t->pipeline_min_n = ctx->pipeline_min_n;
+        t->verify_block = ctx->verify_block;
+        ctx->twin = t;
+    }
+    ctx->twin->timing = ctx->timing;
+    return ctx->twin;
+}
+
 extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->twin) {
+        ssa_ctx_destroy(ctx->twin);
+        ctx->twin = nullptr;
+    }
     // a key set that outlives its context (garbage-collection order of a binding) must not touch the dead stream:
     // its tables are freed here, the handle stays valid for ssa_keyset_destroy and is refused everywhere else
     for (ssa_keyset *ks : ctx->keysets) {
@@ -267,6 +344,34 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+// What the context holds on the device: out[0] window bits and out[1] windows of the comb for G, out[2] its bytes
+// (shared by the contexts of a process), out[3] bytes of this context's workspaces and staging buffers as reserved so
+// far (its second stream's included), out[4] lanes per slice of the per-lane kernels, out[5] signatures per slice of
+// the MSM form, out[6] the HBM budget of the speed-for-memory tables, out[7] 1 when slices alternate between two streams.
+extern "C" int ssa_ctx_info(const ssa_ctx *ctx, uint64_t out[8]) {
+    if (!ctx || !out) return SSA_ERR_ARG;
+    auto reserved = [](const ssa_ctx *c) {
+        uint64_t sum = 0;
+        for (const DevBuf *b : {&c->ws_h, &c->ws_tab, &c->ws_fail, &c->st_sigs, &c->st_pks, &c->st_inf, &c->st_msgs,
+                                &c->st_off, &c->st_status, &c->st_aux, &c->st_aux2, &c->msm_points, &c->msm_scalars,
+                                &c->msm_keys, &c->msm_vals, &c->msm_keys2, &c->msm_vals2, &c->msm_sort_tmp, &c->msm_bounds,
+                                &c->msm_buckets, &c->msm_chunks, &c->msm_windows, &c->msm_partials, &c->msm_flags,
+                                &c->st_coeffs, &c->msm_cnt, &c->msm_cnt2, &c->msm_ids, &c->msm_ids2, &c->msm_comb_pts,
+                                &c->msm_comb_lins, &c->msm_slice_recs, &c->ctab, &c->sg_sigs, &c->sg_pks})
+            sum += b->cap;
+        return sum;
+    };
+    out[0] = ctx->gtab_bits;
+    out[1] = gtab_windows(ctx->gtab_bits);
+    out[2] = gtab_bytes(ctx->gtab_bits);
+    out[3] = reserved(ctx) + (ctx->twin ? reserved(ctx->twin) : 0);
+    out[4] = ctx->lane_slice;
+    out[5] = ctx->msm_slice;
+    out[6] = ctx->hbm_budget;
+    out[7] = ctx->two_streams && !ctx->is_twin ? 1 : 0;
+    return 0;
 }
 
 extern "C" int ssa_ctx_uses_default_params(const ssa_ctx *ctx) { return ctx ? (ctx->default_params ? 1 : 0) : SSA_ERR_ARG; }
@@ -407,7 +512,7 @@ static inline MsgView msg_slice(const MsgView &mv, size_t lo) {
     return s;
 }
 
-// ssa_k_verify over n lanes whose challenge scalars are in d_h, in slices of at most ctx->lane_slice lanes: the 2 KB
+// ssa_k_verify over n lanes whose challenge scalars are in d_h, in slices of at most ctx->lane_slice lanes: the 4 KB
 // per-lane table workspace never exceeds one slice (the caller has reserved it).  *d_fail is added to.
 static int verify_slices(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
                          const u64 *d_h, size_t n, uint32_t flags, uint8_t *d_status_out, unsigned long long *d_fail) {
@@ -425,6 +530,20 @@ static int verify_slices(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_p
     return 0;
 }
 
+// hash + verification of ONE slice (cnt <= c->lane_slice lanes) on c->stream with c's workspaces; *d_fail is added to
+static int verify_one_slice(ssa_ctx *c, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
+                            const MsgView &mv, size_t cnt, uint32_t flags, uint8_t *d_status_out,
+                            unsigned long long *d_fail) {
+    if (c->ws_h.reserve(cnt * 4 * sizeof(u64))) return SSA_ERR_HIP;
+    if (c->ws_tab.reserve(cnt * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
+    int rc = timed_launch(c, "ssa_k_hash", [&] {
+        hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(cnt, 256)), dim3(256), 0, c->stream, c->d_params, d_sigs, d_pks, mv,
+                           cnt, (u64 *)c->ws_h.p, (u8 *)nullptr, (const u32 *)nullptr, 0u);
+    });
+    if (rc) return rc;
+    return verify_slices(c, d_sigs, d_pks, d_pk_inf, (const u64 *)c->ws_h.p, cnt, flags, d_status_out, d_fail);
+}
+
 // the kernels of one verification batch on ctx->stream; *d_fail is added to, not reset
 static int verify_launch(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
                          const uint8_t *d_msgs, const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n,
@@ -439,27 +558,34 @@ static int verify_launch(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_p
                                d_pks, d_pk_inf, mv, (const u64 *)ctx->d_gtab, n, flags, d_status_out, d_fail);
         });
     }
-    // The per-lane workspaces (32 B of challenge scalar, 2 KB of table) are sized for ONE slice of at most
-    // ctx->lane_slice lanes, whatever n is (2.1 GB of tables at the default 2^20; the reference takes slices of any
-    // length, src/batch.rs:31-50): a larger batch runs slice after slice on the stream, into the caller's one status
-    // array and the one rejection counter.  At n <= lane_slice this is the single pair of launches it always was.
+    // The per-lane workspaces (32 B of challenge scalar, 4 KB of table) are sized for ONE slice of at most
+    // ctx->lane_slice lanes, whatever n is (4.3 GB of tables at the default 2^20; the reference takes slices of any
+    // length, src/batch.rs:31-50): a larger batch runs slice after slice, into the caller's one status array and the one
+    // rejection counter.  At n <= lane_slice this is the single pair of launches it always was.
     const size_t slice = ctx->lane_slice < n ? ctx->lane_slice : n;
-    if (ctx->ws_h.reserve(slice * 4 * sizeof(u64))) return SSA_ERR_HIP;
-    if (ctx->ws_tab.reserve(slice * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64) * sizeof(u64))) return SSA_ERR_HIP;
-    for (size_t lo = 0; lo < n; lo += slice) {
-        const size_t cnt = n - lo < slice ? n - lo : slice;
-        const MsgView smv = msg_slice(mv, lo);
-        int rc = timed_launch(ctx, "ssa_k_hash", [&] {
-            hipLaunchKernelGGL(ssa_k_hash, dim3(grid_for(cnt, 256)), dim3(256), 0, ctx->stream, ctx->d_params,
-                               d_sigs + 81 * lo, d_pks + 96 * lo, smv, cnt, (u64 *)ctx->ws_h.p, (u8 *)nullptr,
-                               (const u32 *)nullptr, 0u);
-        });
-        if (rc) return rc;
-        rc = verify_slices(ctx, d_sigs + 81 * lo, d_pks + 96 * lo, d_pk_inf ? d_pk_inf + lo : nullptr,
-                           (const u64 *)ctx->ws_h.p, cnt, flags, d_status_out + lo, d_fail);
-        if (rc) return rc;
+    if (n <= slice) return verify_one_slice(ctx, d_sigs, d_pks, d_pk_inf, mv, n, flags, d_status_out, d_fail);
+    // More than one slice: the slices alternate between the context's stream and its twin's (a second set of
+    // workspaces), so that one slice's kernels fill the tails of the other's -- ordered after everything queued on
+    // ctx->stream before the call, and ctx->stream continues after both.
+    ssa_ctx *tw = ssa_internal_twin(ctx);
+    if (tw) {
+        HIP_TRY(hipEventRecord(ctx->order_ev, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(tw->stream, ctx->order_ev, 0));
     }
-    return 0;
+    int rc = 0;
+    size_t j = 0;
+    for (size_t lo = 0; lo < n && rc == 0; lo += slice, j++) {
+        const size_t cnt = n - lo < slice ? n - lo : slice;
+        ssa_ctx *c = (tw && (j & 1u)) ? tw : ctx;
+        rc = verify_one_slice(c, d_sigs + 81 * lo, d_pks + 96 * lo, d_pk_inf ? d_pk_inf + lo : nullptr, msg_slice(mv, lo), cnt,
+                              flags, d_status_out + lo, d_fail);
+    }
+    if (tw) {     // (also on an error: whatever was queued on the twin's stream is still ordered before the caller's next step)
+        if (hipEventRecord(tw->order_ev, tw->stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->stream, tw->order_ev, 0) != hipSuccess)
+            return rc ? rc : SSA_ERR_HIP;
+    }
+    return rc;
 }
 
 // the throughput (variable-time) signer's launch; arguments checked by the caller (ssa_sign.hip)
@@ -523,14 +649,45 @@ static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_
     return 0;
 }
 
+static int verify_many_host_one(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                                uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out);
+
 extern "C" int ssa_verify_many(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
                                const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride,
                                size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,
                                uint64_t *n_fail_out) {
     if (!ctx || (n && (!sigs || !pks || !status_out))) return SSA_ERR_ARG;
     if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (msg_off)
+        for (size_t i = 0; i < n; i++)
+            if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > 0xffffffffull) return SSA_ERR_ARG;
     if (n_fail_out) *n_fail_out = 0;
     if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n <= ctx->lane_slice)
+        return verify_many_host_one(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, flags, status_out,
+                                    n_fail_out);
+    std::mutex mu;
+    uint64_t total = 0;
+    const int rc = run_host_slices(ctx, n, ctx->lane_slice, [&](ssa_ctx *c, size_t lo, size_t cnt) {
+        const HostMsgSlice ms(msgs, msg_off, msg_stride, lo, cnt);
+        uint64_t nf = 0;
+        const int r = verify_many_host_one(c, sigs + 81 * lo, pks + 96 * lo, pk_inf ? pk_inf + lo : nullptr, ms.msgs, ms.offp,
+                                           msg_stride, msg_len, cnt, flags, status_out + lo, &nf);
+        std::lock_guard<std::mutex> lock(mu);
+        total += nf;
+        return r;
+    });
+    if (rc) return rc;
+    if (n_fail_out) *n_fail_out = total;
+    return 0;
+}
+
+// one slice (n <= ctx->lane_slice, or a batch for the cooperative kernel) from host buffers
+static int verify_many_host_one(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                                const uint8_t *msgs, const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
+                                uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out) {
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t coop_lim = (flags & SSA_FLAG_CHECK_TORSION) ? ctx->coop_max_n_torsion : ctx->coop_max_n;
     const bool lane_kernels = !(flags & SSA_FLAG_FORCE_COOP) && ((flags & SSA_FLAG_FORCE_LANE) || n > coop_lim);
@@ -659,13 +816,43 @@ extern "C" int ssa_decompress_many(ssa_ctx *ctx, const uint8_t *compressed, size
     return 0;
 }
 
+static int verify_keyed_host_one(ssa_ctx *ctx, const uint8_t *keyed, const uint8_t *msgs, const uint64_t *msg_off,
+                                 size_t msg_stride, size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,
+                                 uint64_t *n_fail_out);
+
 extern "C" int ssa_verify_keyed_many(ssa_ctx *ctx, const uint8_t *keyed, const uint8_t *msgs,
                                      const uint64_t *msg_off, size_t msg_stride, size_t msg_len, size_t n,
                                      uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out) {
     if (!ctx || (n && (!keyed || !status_out))) return SSA_ERR_ARG;
     if (int rc = check_msgs(msgs, msg_off, msg_stride, msg_len, n)) return rc;
+    if (msg_off)
+        for (size_t i = 0; i < n; i++)
+            if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > 0xffffffffull) return SSA_ERR_ARG;
     if (n_fail_out) *n_fail_out = 0;
     if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n <= ctx->lane_slice)
+        return verify_keyed_host_one(ctx, keyed, msgs, msg_off, msg_stride, msg_len, n, flags, status_out, n_fail_out);
+    std::mutex mu;
+    uint64_t total = 0;
+    const int rc = run_host_slices(ctx, n, ctx->lane_slice, [&](ssa_ctx *c, size_t lo, size_t cnt) {
+        const HostMsgSlice ms(msgs, msg_off, msg_stride, lo, cnt);
+        uint64_t nf = 0;
+        const int r = verify_keyed_host_one(c, keyed + 130 * lo, ms.msgs, ms.offp, msg_stride, msg_len, cnt, flags,
+                                            status_out + lo, &nf);
+        std::lock_guard<std::mutex> lock(mu);
+        total += nf;
+        return r;
+    });
+    if (rc) return rc;
+    if (n_fail_out) *n_fail_out = total;
+    return 0;
+}
+
+// one slice of KeyedSignature records (n <= ctx->lane_slice) from host buffers
+static int verify_keyed_host_one(ssa_ctx *ctx, const uint8_t *keyed, const uint8_t *msgs, const uint64_t *msg_off,
+                                 size_t msg_stride, size_t msg_len, size_t n, uint32_t flags, uint8_t *status_out,
+                                 uint64_t *n_fail_out) {
     HIP_TRY(hipSetDevice(ctx->device));
     StagedInputs s;
     const void *p;
@@ -719,15 +906,23 @@ extern "C" int ssa_keyset_create_device(ssa_ctx *ctx, const uint8_t *d_pks, cons
         return rc ? rc : SSA_ERR_HIP;
     }
     // few keys: a comb table per key (no doublings at verification time); many keys: the ladder tables only
+    // (100 MB per key: AUTO takes the combs while they fit the context's HBM budget and 16 GiB, and falls back to the
+    // ladder tables when the allocation fails; SSA_KEYSET_COMB insists and reports the failure)
     const size_t comb_bytes = m * KTAB_ENTRIES_PER_KEY * 12 * sizeof(u64);
-    ks->comb = flags == SSA_KEYSET_COMB || (flags == SSA_KEYSET_AUTO && comb_bytes <= ((size_t)16 << 30));
-    if (ks->comb) {
-        DevBuf kbase;                                  // 768 KB per key, only while the combs are assembled
-        if (ks->ktab.reserve(comb_bytes) || kbase.reserve(m * KBASE_ENTRIES_PER_KEY * 12 * sizeof(u64))) {
-            kbase.release();
+    const size_t comb_cap = ctx->hbm_budget < ((uint64_t)16 << 30) ? (size_t)ctx->hbm_budget : ((size_t)16 << 30);
+    ks->comb = flags == SSA_KEYSET_COMB || (flags == SSA_KEYSET_AUTO && comb_bytes <= comb_cap);
+    DevBuf kbase;                                      // 32 x 256 base rows (768 KB) per key, only while the combs are assembled
+    if (ks->comb && (ks->ktab.reserve(comb_bytes) || kbase.reserve(m * KBASE_ENTRIES_PER_KEY * 12 * sizeof(u64)))) {
+        kbase.release();
+        ks->ktab.release();
+        (void)hipGetLastError();
+        if (flags == SSA_KEYSET_COMB) {
             ssa_keyset_destroy(ks);
             return SSA_ERR_HIP;
         }
+        ks->comb = false;
+    }
+    if (ks->comb) {
         rc = timed_launch(ctx, "ssa_k_keycomb_build", [&] {
             hipLaunchKernelGGL(ssa_k_keycomb_base, dim3(grid_for(m * KBASE_ENTRIES_PER_KEY, 256)), dim3(256), 0,
                                ctx->stream, (const u8 *)ks->pks.p, d_pk_inf, (const u8 *)ks->status.p, m,

@@ -686,11 +686,12 @@ COOP_FN u32 coop_verify_two_waves(CoopLds &L, CoopShared &sh, const DevParams *_
 #pragma unroll
             for (int k = 0; k < 4; k++) h.w[k] = sh.h[k];
             coop_mul_table(L, h, lane, ws);                               // [h]P
+            const GtabGeom gg = gtab_geom(gtab);
 #pragma unroll 1
-            for (int w = 0; w < GW_COUNT; w++) {                          // + [e]G, src/signature.rs:196-198
-                const u32 d = sc_gwin(e, (u32)w);
+            for (u32 w = 0; w < gg.count; w++) {                          // + [e]G, src/signature.rs:196-198
+                const u32 d = sc_bits(e, w * gg.bits, gg.bits);
                 if (d != 0) {
-                    const u64 *rowp = gtab + (((size_t)w << GW_BITS) + d) * 12;
+                    const u64 *rowp = gtab + (((size_t)w << gg.bits) + d) * 12;
                     if (lane < 24) {   // lanes 0..11: x, 7x; lanes 12..23: y, 7y
                         const u32 half = lane / 12u, c = lane % 12u;
                         const u64 v = rowp[6u * half + c % 6u];

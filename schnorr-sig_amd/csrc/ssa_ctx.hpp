@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -68,8 +70,14 @@ struct ssa_ctx {
     size_t pipeline_min_n = 1 << 17;          // host-buffer batches from this size on are uploaded in chunks
     unsigned pipeline_chunks = 8;             // SSA_PIPELINE_CHUNKS overrides (1 = off)
     DevParams *d_params = nullptr;
-    u64 *d_gtab = nullptr;                    // the comb table for G: owned by gtab_share (one per device and generator)
-    struct SharedGtab *gtab_share = nullptr;
+    u64 *d_gtab = nullptr;                    // the comb table for G: owned by gtab_share (one per device, generator and
+    struct SharedGtab *gtab_share = nullptr;  //   geometry); its first word carries the geometry (ssa_kernels.hpp)
+    uint32_t gtab_bits = 0;                   // window width of that table (16 / 20 / 22 / 24)
+    uint64_t hbm_budget = 0;                  // bytes the speed-for-memory tables may take (comb for G, per-key combs)
+    DevParams h_params;                       // host copy of the blob the context was created from (derived flags set)
+    ssa_ctx *twin = nullptr;                  // second set of streams and workspaces: calls of more than one slice
+                                              //   alternate their slices between the two (created at the first such call)
+    bool is_twin = false, two_streams = true; // SSA_TWO_STREAMS=0 turns the alternation off
     DevBuf ws_h, ws_tab, ws_fail;
     // staging for the host-buffer entry points
     DevBuf st_sigs, st_pks, st_inf, st_msgs, st_off, st_status, st_aux, st_aux2;
@@ -294,4 +302,59 @@ static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const
 // defined in ssa_api.hip: hash_message + Scalar::from_bits_vartime for n signatures into ctx->ws_h
 int ssa_internal_hash_scalars(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
                               const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n);
+
+// defined in ssa_api.hip: the context's second set of streams and workspaces (nullptr: none -- a twin itself, turned
+// off, or no memory for it)
+ssa_ctx *ssa_internal_twin(ssa_ctx *ctx);
+
+// Host-buffer batches in bounded device memory (round 5): more than one slice of lanes runs slice after slice through
+// staging buffers sized for ONE slice, pinning only the slice in flight, into the caller's one status array and one
+// counter -- fn(c, lo, cnt) is the one-slice form of the entry point on context c.  With a twin (ssa_internal_twin) two host
+// threads take alternate slices, one on the context and one on its twin: the upload of a slice runs under the kernels
+// of the other, and the kernels' tails fill each other.
+template <class F>
+static int run_host_slices(ssa_ctx *ctx, size_t n, size_t slice, F &&fn) {
+    const size_t k = (n + slice - 1) / slice;
+    ssa_ctx *tw = k > 1 ? ssa_internal_twin(ctx) : nullptr;
+    if (!tw) {
+        for (size_t j = 0; j < k; j++) {
+            const size_t lo = j * slice, cnt = n - lo < slice ? n - lo : slice;
+            if (int rc = fn(ctx, lo, cnt)) return rc;
+        }
+        return 0;
+    }
+    int rcs[2] = {0, 0};
+    auto worker = [&](size_t w) {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            rcs[w] = SSA_ERR_HIP;
+            return;
+        }
+        ssa_ctx *c = w ? tw : ctx;
+        for (size_t j = w; j < k && rcs[w] == 0; j += 2) {
+            const size_t lo = j * slice, cnt = n - lo < slice ? n - lo : slice;
+            rcs[w] = fn(c, lo, cnt);
+        }
+    };
+    std::thread second(worker, (size_t)1);
+    worker(0);
+    second.join();
+    return rcs[0] ? rcs[0] : rcs[1];
+}
+
+// the messages of lanes [lo, lo + cnt) of a host batch as a batch of their own (an offset table is rebased)
+struct HostMsgSlice {
+    std::vector<uint64_t> off;
+    const uint8_t *msgs = nullptr;
+    const uint64_t *offp = nullptr;
+    HostMsgSlice(const uint8_t *all, const uint64_t *msg_off, size_t msg_stride, size_t lo, size_t cnt) {
+        if (msg_off) {
+            off.resize(cnt + 1);
+            for (size_t k = 0; k <= cnt; k++) off[k] = msg_off[lo + k] - msg_off[lo];
+            msgs = all ? all + msg_off[lo] : nullptr;
+            offp = off.data();
+        } else {
+            msgs = all ? all + lo * msg_stride : nullptr;
+        }
+    }
+};
 

@@ -14,7 +14,8 @@
 //                           line is scratch of the batch normalisation and holds the NEGATIVE entry (x, -y) once the
 //                           table is finished), lane-contiguous so that a lane's gather of one entry -- of either
 //                           sign -- is six 16-byte loads from ONE cache line
-//   gtab    11 x 2^24 x 12 u64 affine multiples d*2^(24w)*G (17.7 GB, shared by the contexts of a process)
+//   gtab    count x 2^bits x 12 u64 affine multiples d*2^(bits*w)*G -- 11 x 2^24 rows (17.7 GB) where HBM allows, down to
+//           16 x 2^16 (100 MB); the geometry is a property of the table (its first row), chosen per context
 #pragma once
 #include "curve.hpp"
 #include "fp3.hpp"
@@ -22,17 +23,30 @@
 
 namespace ssa {
 
-// Fixed-base comb for G: gtab[w][d] = affine [d 2^(24 w)] G, 11 windows of 24 bits -- [e]G is 11 mixed additions and no
-// doubling (round 4; 16 windows of 16 bits and 16 additions before).  17.7 GB, ONE per device and generator shared by the
-// contexts of a process: sized for the 288 GB of the part, not for a cache -- a lane gathers 11 rows in 13 ms of ladder,
-// the second wave of the SIMD covers the misses.  (Measured: 16 bits 27.08 ms, 22 bits 26.70, 24 bits 26.57 for ssa_k_verify.)
-constexpr int GW_BITS = 24;
-constexpr int GW_COUNT = 11;
-constexpr size_t GTAB_ENTRIES = (size_t)GW_COUNT << GW_BITS;
-// the table is assembled from two small ones per window: gbase[w][h][d] = [d 2^(24 w + 12 h)] G, d < 4096
-constexpr int GB_BITS = GW_BITS / 2;
-constexpr size_t GBASE_ENTRIES = (size_t)GW_COUNT * 2 << GB_BITS;
-SSA_DEV u32 sc_gwin(const sc256 &k, u32 w) { return sc_bits(k, w * (u32)GW_BITS, (u32)GW_BITS); }
+// Fixed-base comb for G: gtab[w][d] = affine [d 2^(bits w)] G, `count` windows of `bits` bits -- [e]G is `count` mixed
+// additions and no doubling.  The geometry is a property of the TABLE, not of the build (round 5; a compile-time 24 / 11
+// in round 4): 24 bits x 11 windows = 17.7 GB (ssa_k_verify 26.57 ms), 22 x 12 = 4.8 GB (26.70), 20 x 13 = 1.3 GB,
+// 16 x 16 = 100 MB (27.08): ssa_ctx_create takes the widest that fits its HBM budget and falls back when the allocation
+// fails.  ONE table per device, generator and geometry, shared by the contexts of a process: sized for the 288 GB of the
+// part, not for a cache -- a lane gathers 11 rows in 13 ms of ladder, the second wave of the SIMD covers the misses.
+// The table describes itself: row 0 of window 0 is the identity row that no digit ever selects (a zero digit skips the
+// addition), and its first word carries bits | count << 8 -- every kernel that walks the comb reads the geometry
+// from the table it was handed, so a table and its geometry cannot be mixed up.
+struct GtabGeom {
+    u32 bits, count;
+};
+constexpr int GW_BITS_MAX = 24, GW_BITS_MIN = 16;
+__host__ __device__ inline u32 gtab_windows(u32 bits) { return (255u + bits) / bits; }           // bits * count >= 256
+__host__ __device__ inline size_t gtab_entries(u32 bits) { return (size_t)gtab_windows(bits) << bits; }
+__host__ __device__ inline size_t gbase_entries(u32 bits) { return ((size_t)gtab_windows(bits) * 2) << (bits / 2); }
+__host__ __device__ inline u64 gtab_header(u32 bits) { return (u64)bits | ((u64)gtab_windows(bits) << 8); }
+SSA_DEV GtabGeom gtab_geom(const u64 *__restrict__ gtab) {
+    const u64 v = gtab[0];
+    GtabGeom g;
+    g.bits = (u32)(v & 0xffu);
+    g.count = (u32)((v >> 8) & 0xffu);
+    return g;
+}
 constexpr int PTAB_ENTRIES = 16;    // 1P..16P: signed 5-bit windows (round 4; 1P..8P and 4-bit windows before)
 // a table row is 256 B = two 128-B lines: X, Y (affine x, y after the build) in the first -- a gather of the
 // ladder touches exactly one line -- and Z, prefix product of the build in the second
@@ -465,13 +479,14 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q =
     return acc;
 }
 
-// acc += [e]G from the comb table: one mixed addition per non-zero 24-bit window
+// acc += [e]G from the comb table: one mixed addition per non-zero window of e (the table's own geometry)
 SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e) {
+    const GtabGeom gg = gtab_geom(gtab);
 #pragma unroll 1
-    for (int w = 0; w < GW_COUNT; w++) {
-        const u32 d = sc_gwin(e, (u32)w);
+    for (u32 w = 0; w < gg.count; w++) {
+        const u32 d = sc_bits(e, w * gg.bits, gg.bits);
         if (d != 0) {
-            const aff q = ld_aff(gtab + (((size_t)w << GW_BITS) + d) * 12);
+            const aff q = ld_aff(gtab + (((size_t)w << gg.bits) + d) * 12);
             acc = jac_madd_fast(acc, q);
         }
     }
@@ -833,19 +848,21 @@ ssa_k_verify_keyed_comb(const u8 *__restrict__ sigs, const u32 *__restrict__ key
 
 // ------------------------------------------------------------------------------------------
 // The comb table in two steps (round 4; one double-and-add chain of ~250 doublings PER ENTRY before: 13.5 ms for 2^20
-// entries, which would be 2.5 s for the 1.8 * 10^8 of the 24-bit table):
-//   ssa_k_gbase   gbase[w][h][d] = affine [d 2^(24 w + 12 h)] G for d < 4096: 90 112 entries the slow way (1.3 ms)
-//   ssa_k_gtable  gtab[w][d] = gbase[w][1][d >> 12] + gbase[w][0][d & 4095]: ONE affine addition per entry, a lane
-//                 takes 8 consecutive entries (same high part) and inverts their 8 denominators together (23 ms in all);
-//                 no exceptional case can occur between the two parts (d_hi 2^12 = +-d_lo (mod q) has no solution below
-//                 2^24), only zero
-//                 parts, which copy the other one.  d = 0 rows are (0, 0) and are never read.
+// entries, which would be 2.5 s for the 1.8 * 10^8 of the 24-bit table), for a geometry of `bits` (even) x count windows:
+//   ssa_k_gbase   gbase[w][h][d] = affine [d 2^(bits w + bits/2 h)] G for d < 2^(bits/2): the slow way (90 112 entries
+//                 and 1.3 ms for 24 bits)
+//   ssa_k_gtable  gtab[w][d] = gbase[w][1][d >> bits/2] + gbase[w][0][d & (2^(bits/2) - 1)]: ONE affine addition per
+//                 entry, a lane takes 8 consecutive entries (same high part) and inverts their 8 denominators together
+//                 (23 ms in all for 24 bits); no exceptional case can occur between the two parts (d_hi 2^(bits/2) =
+//                 +-d_lo (mod q) has no solution below 2^bits), only zero parts, which copy the other one.  d = 0 rows
+//                 are (0, 0) and are never read as points; row 0 of window 0 carries the geometry (gtab_header).
 #ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256)
-ssa_k_gbase(const DevParams *__restrict__ prm, u64 *__restrict__ gbase) {
+ssa_k_gbase(const DevParams *__restrict__ prm, u64 *__restrict__ gbase, u32 bits) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= GBASE_ENTRIES) return;
-    const u32 d = (u32)(t & ((1u << GB_BITS) - 1u)), wh = (u32)(t >> GB_BITS);   // wh = 2 w + h
+    if (t >= gbase_entries(bits)) return;
+    const u32 hb = bits / 2;
+    const u32 d = (u32)(t & ((1u << hb) - 1u)), wh = (u32)(t >> hb);   // wh = 2 w + h
     aff g;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -854,26 +871,28 @@ ssa_k_gbase(const DevParams *__restrict__ prm, u64 *__restrict__ gbase) {
     }
     jac acc = jac_identity();
 #pragma unroll 1
-    for (int b = GB_BITS - 1; b >= 0; b--) {
+    for (int b = (int)hb - 1; b >= 0; b--) {
         acc = jac_dbl(acc);
         if ((d >> b) & 1u) acc = jac_madd(acc, g);
     }
 #pragma unroll 1
-    for (u32 s = 0; s < wh * GB_BITS; s++) acc = jac_dbl(acc);
+    for (u32 s = 0; s < wh * hb; s++) acc = jac_dbl(acc);
     st_aff(gbase + t * 12, jac_to_aff(acc));          // the identity (d = 0) as (0, 0)
 }
 
 __global__ void __launch_bounds__(256)
-ssa_k_gtable(const u64 *__restrict__ gbase, u64 *__restrict__ gtab) {
+ssa_k_gtable(const u64 *__restrict__ gbase, u64 *__restrict__ gtab, u32 bits) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= GTAB_ENTRIES / 8) return;
-    const u32 w = (u32)((t * 8) >> GW_BITS), d0 = (u32)((t * 8) & ((1u << GW_BITS) - 1u));
-    const u32 dhi = d0 >> GB_BITS, dlo0 = d0 & ((1u << GB_BITS) - 1u);
-    const u64 *slo = gbase + ((size_t)(2 * w) << GB_BITS) * 12, *shi = gbase + ((size_t)(2 * w + 1) << GB_BITS) * 12;
-    u64 *out = gtab + (((size_t)w << GW_BITS) + d0) * 12;
+    if (t >= gtab_entries(bits) / 8) return;
+    const u32 hb = bits / 2;
+    const u32 w = (u32)((t * 8) >> bits), d0 = (u32)((t * 8) & ((1u << bits) - 1u));
+    const u32 dhi = d0 >> hb, dlo0 = d0 & ((1u << hb) - 1u);
+    const u64 *slo = gbase + ((size_t)(2 * w) << hb) * 12, *shi = gbase + ((size_t)(2 * w + 1) << hb) * 12;
+    u64 *out = gtab + (((size_t)w << bits) + d0) * 12;
     if (dhi == 0) {                                   // only the low part: copies (row 0 of gbase is (0, 0))
 #pragma unroll 1
         for (int k = 0; k < 8; k++) st_aff(out + 12 * k, ld_aff(slo + (size_t)(dlo0 + k) * 12));
+        if (t == 0) out[0] = gtab_header(bits);       // the identity row of window 0 describes the table
         return;
     }
     const aff p1 = ld_aff(shi + (size_t)dhi * 12);

@@ -295,6 +295,27 @@ ssa_k_sign_ct(const DevParams *__restrict__ prm, const u64 *__restrict__ ctab, c
     for (int k = 0; k < 4; k++) st_u64_le(sig + 49 + 8 * k, e.w[k]);
 }
 
+// PublicKey::from(&PrivateKey) (src/public.rs:26-32): pk = [sk]G and nothing else -- ONE constant-time base
+// multiplication, no nonce, no hash, no response scalar: nothing derived from sk but the public key leaves the lane.
+// (Round 4's mirrors obtained the key from the signer with nonce = sk, whose discarded response e = sk (1 - h) is as
+// good as the private key: ADVICE r4.)
+__global__ void __launch_bounds__(256, 2)
+ssa_k_pubkey_ct(const u64 *__restrict__ ctab, const u64 *__restrict__ gtab, const u8 *__restrict__ sks, size_t n,
+                u8 *__restrict__ pks_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sc256 sk;
+    ct_load_scalar(&sk, sks + 32 * i);
+    jac pj;
+    bool bad_p;
+    ct_base_mul(&pj, &bad_p, ctab, &sk);
+    if (bad_p) pj = add_base_mul(jac_identity(), gtab, sk);      // sk = 0 (refused by the host form) or a 2^-250 event
+    aff pk;
+    ct_to_aff(&pk, &pj);
+    st_fp6(pks_out + 96 * i, pk.x);
+    st_fp6(pks_out + 96 * i + 48, pk.y);
+}
+
 // AffinePoint::to_compressed + CompressedPoint::to_bytes (PublicKey::to_bytes, src/public.rs:49-51): x || flag byte
 // (bit 7 infinity -- [0; 48] || 0x80, src/public.rs:95-101 --, bit 6 the sort flag of y).  status: 0, or SSA_MALFORMED
 // for a limb that is not canonical (an AffinePoint cannot hold one)
@@ -343,14 +364,31 @@ int ssa_internal_sign_vartime(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t 
                               const uint64_t *d_msg_off, size_t msg_stride, size_t msg_len, size_t n, uint8_t *d_pks_out,
                               uint8_t *d_sigs_out);     // ssa_api.hip: the throughput signer's launch
 
+// the 98 KB table of the constant-time signer, built once per context -- and COMPLETE before the call returns: a later
+// call may run on another stream (ssa_ctx_set_stream), and a failed build must not leave a table marked ready
 static int ensure_ctab(ssa_ctx *ctx) {
     if (ctx->ctab_ready) return 0;
     if (ctx->ctab.reserve(CTAB_ROWS * 12 * sizeof(u64))) return SSA_ERR_HIP;
     hipLaunchKernelGGL(ssa_k_ctab, dim3(grid_for(CTAB_ROWS, 64)), dim3(64), 0, ctx->stream, (const u64 *)ctx->d_gtab,
                        (u64 *)ctx->ctab.p);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->ctab_ready = true;
     return 0;
+}
+
+// PublicKey::from(&PrivateKey) for n secret keys (device buffers; the caller guarantees canonical non-zero scalars --
+// the host form checks them: a zero or non-canonical value is still computed correctly, [sk mod q]G, but through the
+// variable-time fallback)
+extern "C" int ssa_pubkey_many_device(ssa_ctx *ctx, const uint8_t *d_sks, size_t n, uint8_t *d_pks_out) {
+    if (!ctx || (n && (!d_sks || !d_pks_out)) || n > SSA_MAX_BATCH) return SSA_ERR_ARG;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = ensure_ctab(ctx)) return rc;
+    return timed_launch(ctx, "ssa_k_pubkey_ct", [&] {
+        hipLaunchKernelGGL(ssa_k_pubkey_ct, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, (const u64 *)ctx->ctab.p,
+                           (const u64 *)ctx->d_gtab, d_sks, n, d_pks_out);
+    });
 }
 
 extern "C" int ssa_keygen_sign_many_ex_device(ssa_ctx *ctx, const uint8_t *d_sks, const uint8_t *d_nonces,
@@ -436,6 +474,28 @@ static bool scalars_canonical_nonzero(const uint8_t *v, size_t n) {
         all_ok &= borrow & (unsigned)(nonzero != 0);
     }
     return all_ok != 0;
+}
+
+extern "C" int ssa_pubkey_many(ssa_ctx *ctx, const uint8_t *sks, size_t n, uint8_t *pks_out) {
+    if (!ctx || (n && (!sks || !pks_out)) || n > SSA_MAX_BATCH) return SSA_ERR_ARG;
+    if (n == 0) return 0;
+    if (!scalars_canonical_nonzero(sks, n)) return SSA_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    struct Wipe {      // the staged secrets do not outlive the call, whichever way it returns
+        ssa_ctx *ctx;
+        size_t bytes;
+        ~Wipe() {
+            if (ctx->st_sigs.p && ctx->st_sigs.cap >= bytes) (void)hipMemsetAsync(ctx->st_sigs.p, 0, bytes, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+    } wipe{ctx, n * 32};
+    const void *p_sk;
+    if (int rc = stage_up(ctx, ctx->st_sigs, sks, n * 32, &p_sk)) return rc;
+    if (ctx->st_aux.reserve(n * 96)) return SSA_ERR_HIP;
+    if (int rc = ssa_pubkey_many_device(ctx, (const u8 *)p_sk, n, (u8 *)ctx->st_aux.p)) return rc;
+    HIP_TRY(hipMemcpyAsync(pks_out, ctx->st_aux.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 extern "C" int ssa_keygen_sign_many_ex(ssa_ctx *ctx, const uint8_t *sks, const uint8_t *nonces, const uint8_t *msgs,

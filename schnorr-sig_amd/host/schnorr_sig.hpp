@@ -49,12 +49,15 @@ using Rng = std::function<void(uint8_t *, size_t)>;  // fills a buffer with rand
 
 class Context {
   public:
-    explicit Context(int device = 0, const void *params = nullptr, size_t params_len = 0) {
+    // gtab_bits / hbm_budget_bytes: the comb for G (the reference's const BASEPOINT_TABLE) as a speed-for-memory choice of
+    // the context -- 0 / 0 = the widest table that fits a tenth of the free device memory (ssa_ctx_create_ex)
+    explicit Context(int device = 0, const void *params = nullptr, size_t params_len = 0, uint32_t gtab_bits = 0,
+                     uint64_t hbm_budget_bytes = 0) {
         // a library from another revision of the header links just as well and reads its arguments shifted
         if (ssa_abi_version() != SSA_ABI_VERSION)
             throw std::runtime_error("schnorr_sig_amd: library ABI version " + std::to_string(ssa_abi_version()) +
                                      ", header " + std::to_string(SSA_ABI_VERSION));
-        int rc = ssa_ctx_create(&ctx_, device, params, params_len);
+        int rc = ssa_ctx_create_ex(&ctx_, device, params, params_len, gtab_bits, hbm_budget_bytes);
         if (rc != 0) throw std::runtime_error(std::string("ssa_ctx_create: ") + ssa_strerror(rc));
     }
     ~Context() { ssa_ctx_destroy(ctx_); }
@@ -239,14 +242,13 @@ struct KeyPair {  // src/keypair.rs:48-53
         }
     }
     bool operator==(const KeyPair &o) const { return private_key == o.private_key && public_key == o.public_key; }
-    // impl From<&PrivateKey> for KeyPair, src/keypair.rs:21-32: the public key is [sk]G, computed by the constant-time signer
+    // impl From<&PrivateKey> for KeyPair, src/keypair.rs:21-32: the public key is [sk]G -- one constant-time base
+    // multiplication (ssa_pubkey_many) and nothing else derived from the secret
     static KeyPair from_private(Context &cx, const PrivateKey &sk) {
         KeyPair kp;
         kp.private_key = sk;
-        uint8_t sig[SIGNATURE_LENGTH], msg = 0;
-        int rc = ssa_keygen_sign_many_ex(cx.get(), sk.bytes.data(), sk.bytes.data(), &msg, nullptr, 1, 1, 1, SSA_FLAG_SIGN_CT,
-                                         kp.public_key.affine.data(), sig);
-        if (rc != 0) throw std::runtime_error(std::string("ssa_keygen_sign_many_ex: ") + ssa_strerror(rc));
+        int rc = ssa_pubkey_many(cx.get(), sk.bytes.data(), 1, kp.public_key.affine.data());
+        if (rc != 0) throw std::runtime_error(std::string("ssa_pubkey_many: ") + ssa_strerror(rc));
         return kp;
     }
     // KeyPair::to_bytes / from_bytes / from_seed, src/keypair.rs:73-103: the private key only, the public key is rebuilt
