@@ -92,9 +92,35 @@ def test_secret_dependent_code_has_no_data_dependent_control_flow():
             if ln.startswith("s_cbranch_scc"):
                 prev = [x for x in lines[max(0, i - 400):i] if x.startswith(("s_cmp", "s_and", "s_or", "s_xor", "s_bitcmp"))]
                 assert prev and re.match(r"s_cmpk?_(eq|lg|lt|gt|le|ge)_[ui]32 s\d+, (0x[0-9a-f]+|-?\d+)$", prev[-1]), (name, ln, prev[-3:])
-    # the kernel itself calls them (they were not folded into the kernel body, where public-data branches live)
+    # the closure of the secret-dependent code is the checked set: every call out of a checked body goes to a checked body
+    # (a compiler or an edit that outlines f6_inv, sc_mul_4x4, ... would otherwise escape the check while it stays green),
+    # and every call is a direct one (s_swappc through a pc-relative symbol: one @rel32@lo per s_swappc)
+    for name in SECRET_FUNCS:
+        body = fns[name]
+        pairs = {}                       # SGPR pair -> the function whose address it holds (set up pc-relative, maybe copied)
+        for ln in (x.strip() for x in body.splitlines()):
+            m = re.match(r"s_add_u32 s(\d+), s\1, _ZN3ssa(\d+)(\w+)@rel32@lo", ln)
+            if m:
+                pairs["s[%d:%d]" % (int(m.group(1)), int(m.group(1)) + 1)] = m.group(3)[:int(m.group(2))]
+                continue
+            m = re.match(r"s_mov_b64 (s\[\d+:\d+\]), (s\[\d+:\d+\])$", ln)
+            if m and m.group(2) in pairs:
+                pairs[m.group(1)] = pairs[m.group(2)]
+                continue
+            m = re.match(r"s_swappc_b64 s\[30:31\], (s\[\d+:\d+\])$", ln)
+            if m:
+                assert m.group(1) in pairs, "%s: call through %s, which holds no pc-relative symbol (indirect?)" % (name, m.group(1))
+                assert pairs[m.group(1)] in SECRET_FUNCS, "%s calls %s, which is not in the checked set" % (name, pairs[m.group(1)])
+            else:
+                assert not ln.startswith("s_swappc"), (name, ln)
+        assert not re.search(r"^\s*s_setpc_b64 (?!s\[30:31\])", body, flags=re.M), name       # only the return
+    # the kernels themselves call them (they were not folded into the kernel bodies, where public-data branches live)
     kern = fns["ssa_k_sign_ct"]
     assert kern.count("s_swappc_b64") >= 6
+    pub = fns["ssa_k_pubkey_ct"]         # PublicKey::from(&PrivateKey): load, one base multiplication, to affine
+    called = {rest[:int(ln)] for _, ln, rest in re.findall(r"(_ZN3ssa(\d+)(\w+))@rel32@lo", pub)}
+    assert {"ct_load_scalar", "ct_base_mul", "ct_to_aff"} <= called, called
+    assert "ct_response" not in called and "hash_message_lane" not in called
 
 
 def test_table_scan_reads_every_entry_and_selects():
