@@ -54,6 +54,12 @@ int main(int argc, char **argv) {
     for (int i = 0; i < N; i++) CHECK(st[i] == SO_OK);
     CHECK(so_verify_batch_msm(sigs, pks, inf, msgs, NULL, ML, ML, N, co, 2) == SO_OK);
     CHECK(so_verify_batch_msm(sigs, pks, NULL, msgs, NULL, ML, ML, 0, co, 1) == SO_OK);   /* empty batch */
+    /* the timing path (schnorr_oracle_fast.inc): the same answers out of exact-size blocks */
+    so_verify_many_fast(sigs, pks, inf, msgs, NULL, ML, ML, N, 1, 2, st);
+    for (int i = 0; i < N; i++) CHECK(st[i] == SO_OK);
+    CHECK(so_verify_batch_msm_fast(sigs, pks, inf, msgs, NULL, ML, ML, N, co, 2) == SO_OK);
+    CHECK(so_verify_batch_msm_fast(sigs, pks, NULL, msgs, NULL, ML, ML, 0, co, 1) == SO_OK);
+    CHECK(so_verify_batch_msm_fast(sigs, pks, inf, msgs, NULL, ML, ML, 1, co, 1) == SO_OK);
 
     /* single-signature entry points agree with the batch ones */
     uint8_t pk1[96], sig1[81];
@@ -75,6 +81,16 @@ int main(int argc, char **argv) {
     so_verify_many(sigs, pks, inf, msgs, NULL, ML, ML, N, 0, 3, st);
     CHECK(st[0] == 0 && st[1] == 2 && st[2] == 2 && st[3] == 2 && st[4] == 0 && st[5] == 3 && st[6] == 3);
     CHECK(so_verify_batch_msm(sigs, pks, inf, msgs, NULL, ML, ML, N, co, 2) == SO_MALFORMED);
+    {
+        uint8_t *st2 = malloc(N);
+        so_verify_many_fast(sigs, pks, inf, msgs, NULL, ML, ML, N, 0, 3, st2);
+        CHECK(memcmp(st, st2, N) == 0);
+        so_verify_many_fast(sigs, pks, inf, msgs, NULL, ML, ML, N, 1 | 8, 1, st2);
+        so_verify_many(sigs, pks, inf, msgs, NULL, ML, ML, N, 1 | 8, 1, st);
+        CHECK(memcmp(st, st2, N) == 0);
+        free(st2);
+        CHECK(so_verify_batch_msm_fast(sigs, pks, inf, msgs, NULL, ML, ML, N, co, 2) == SO_MALFORMED);
+    }
     uint8_t keep = sigs[81 * 7 + 48];
     sigs[81 * 7 + 48] = 0xff;                                                              /* src/public.rs:150-156 */
     CHECK(so_verify(sigs + 81 * 7, pks + 96 * 7, 0, msgs + ML * 7, ML, 8) == SO_MALFORMED);
@@ -92,6 +108,11 @@ int main(int argc, char **argv) {
     so_verify_many(sigs, pks, inf, flat, off, 0, 0, N, 1 | 8, 0, st);
     for (int i = 0; i < 8; i++) CHECK(st[i] == SO_OK);
     CHECK(st[8] == SO_INVALID_SIGNATURE);
+    so_verify_many_fast(sigs, pks, inf, flat, off, 0, 0, N, 1 | 8, 0, st);
+    for (int i = 0; i < 8; i++) CHECK(st[i] == SO_OK);
+    CHECK(st[8] == SO_INVALID_SIGNATURE);
+    CHECK(so_verify_batch_msm_fast(sigs, pks, inf, flat, off, 0, 0, N, co, 1) ==
+          so_verify_batch_msm(sigs, pks, inf, flat, off, 0, 0, N, co, 1));
     inf[8] = 0;
 
     /* compression round trip, identity encoding (src/public.rs:95-101), undecodable x = 0 (:115-120) */

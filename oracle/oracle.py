@@ -190,6 +190,32 @@ class Oracle:
                                 int(bool(check_torsion)) | (8 if sig_flag_byte else 0), int(threads), _ptr(st, _u8p))
         return st
 
+    def verify_many_fast(self, sigs, pks, msgs, offsets=None, check_torsion=True, threads=0, pk_inf=None,
+                         sig_flag_byte=False):
+        """verify_many through the TIMING path (windowed / lazy-reduction algorithms): same statuses"""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 81)
+        pks = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, 96)
+        n = sigs.shape[0]
+        msgs, off, stride, mlen = self._msgs(msgs, offsets, n)
+        inf = np.ascontiguousarray(pk_inf, dtype=np.uint8) if pk_inf is not None else None
+        st = np.zeros(n, np.uint8)
+        self.lib.so_verify_many_fast(_ptr(sigs, _u8p), _ptr(pks, _u8p), _ptr(inf, _u8p), _ptr(msgs, _u8p),
+                                     _ptr(off, _u64p), C.c_size_t(stride), C.c_size_t(mlen), C.c_size_t(n),
+                                     int(bool(check_torsion)) | (8 if sig_flag_byte else 0), int(threads), _ptr(st, _u8p))
+        return st
+
+    def verify_batch_msm_fast(self, sigs, pks, msgs, coeffs, offsets=None, threads=0, pk_inf=None):
+        """verify_batch_msm through the TIMING path (bucket MSM): same verdict"""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 81)
+        pks = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, 96)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint8).reshape(-1, 32)
+        n = sigs.shape[0]
+        msgs, off, stride, mlen = self._msgs(msgs, offsets, n)
+        inf = np.ascontiguousarray(pk_inf, dtype=np.uint8) if pk_inf is not None else None
+        return int(self.lib.so_verify_batch_msm_fast(_ptr(sigs, _u8p), _ptr(pks, _u8p), _ptr(inf, _u8p), _ptr(msgs, _u8p),
+                                                     _ptr(off, _u64p), C.c_size_t(stride), C.c_size_t(mlen),
+                                                     C.c_size_t(n), _ptr(coeffs, _u8p), int(threads)))
+
     def keygen_sign_many(self, sks, nonces, msgs, offsets=None, threads=0):
         sks = np.ascontiguousarray(sks, dtype=np.uint8).reshape(-1, 32)
         nonces = np.ascontiguousarray(nonces, dtype=np.uint8).reshape(-1, 32)

@@ -382,6 +382,7 @@ static void wr64(uint8_t *p, u64 v) {
     for (int k = 0; k < 8; k++) p[k] = (uint8_t)(v >> (8 * k));
 }
 
+static void fast_init(void);
 int so_init(const uint8_t *blob, size_t len) {
     if (len != 2816 || memcmp(blob, "SSAPARM1", 8) != 0) return -1;
     uint32_t hdr[6];
@@ -426,6 +427,7 @@ int so_init(const uint8_t *blob, size_t len) {
     if (!pt_on_curve(G_J.x, G_J.y)) return -2;
     j_table16(&G_J, G_TAB);
     PRM.ready = 1;
+    fast_init();      /* tables of the timing path (schnorr_oracle_fast.inc) */
     return 0;
 }
 
@@ -798,3 +800,6 @@ void so_compress(const uint8_t pk96[96], int pk_inf, uint8_t c49[49]) {
     fp6_from_bytes48(pk96 + 48, &y);
     c49[48] = fp6_lex_largest(y) ? 0x40 : 0;
 }
+
+/* ------------------------------------------------------------------ the timing path of the CPU baseline */
+#include "schnorr_oracle_fast.inc"

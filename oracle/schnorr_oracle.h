@@ -69,6 +69,15 @@ void so_keygen_sign_many(const uint8_t *sks, const uint8_t *nonces, const uint8_
 int so_verify_batch_msm(const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf, const uint8_t *msgs,
                         const uint64_t *off, size_t stride, size_t msg_len, size_t n,
                         const uint8_t *coeffs, int threads);
+/* The same two calls with the algorithms a CPU library would use (schnorr_oracle_fast.inc: lazy Fp6 products, width-5
+ * NAF over affine odd multiples, a fixed-base table for G, a bucket MSM) -- the TIMING path of bench.py's cpu_baseline
+ * leg, cross-checked against the plain functions above on every sample it times.  Identical results on every input. */
+void so_verify_many_fast(const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf,
+                         const uint8_t *msgs, const uint64_t *off, size_t stride, size_t msg_len,
+                         size_t n, int flags, int threads, uint8_t *status);
+int so_verify_batch_msm_fast(const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_inf, const uint8_t *msgs,
+                             const uint64_t *off, size_t stride, size_t msg_len, size_t n,
+                             const uint8_t *coeffs, int threads);
 int so_hw_threads(void);
 int so_decompress(const uint8_t c49[49], uint8_t pk96[96], int *pk_inf);
 void so_compress(const uint8_t pk96[96], int pk_inf, uint8_t c49[49]);
