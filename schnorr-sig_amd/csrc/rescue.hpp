@@ -186,6 +186,12 @@ SSA_DEV void mds_ark_tiny(const u64 *src, u64 *dst, const u64 *__restrict__ mds,
     u64 v[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) v[j] = src[j * RS_STRIDE];
+#ifdef SSA_MDS_FREE      // TIMING EXPERIMENT ONLY (wrong digests): the layer for free -- one add per row, the LDS round trip
+    (void)mds;            // kept -- bounds what ANY other evaluation of the matrix product (MFMA, dot4) could save
+#pragma unroll
+    for (int i = 0; i < 12; i++) dst[i * RS_STRIDE] = v[i] + ark[i];
+    return;
+#endif
 #pragma unroll 1
     for (int i = 0; i < 12; i++) {
         const u64 *row = mds + i * 12;

@@ -189,6 +189,7 @@ extern "C" int ssa_ctx_create_ex(ssa_ctx **out, int device, const void *params, 
         if (v >= 2 && v <= 64) ctx->msm_tree_group = (unsigned)v;
     }
     if (const char *ts = std::getenv("SSA_TWO_STREAMS")) ctx->two_streams = std::atoi(ts) != 0;
+    if (const char *mo = std::getenv("SSA_MSM_OVERLAP")) ctx->msm_overlap = std::atoi(mo) != 0;
     if (const char *pc = std::getenv("SSA_PIPELINE_CHUNKS")) {
         const int v = std::atoi(pc);
         if (v >= 1 && v <= 8) ctx->pipeline_chunks = (unsigned)v;
@@ -327,7 +328,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
                       &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
                       &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
-                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks})
+                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->msm_sbuf, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     gtab_release(ctx->gtab_share);
@@ -359,7 +360,7 @@ extern "C" int ssa_ctx_info(const ssa_ctx *ctx, uint64_t out[8]) {
                                 &c->msm_keys, &c->msm_vals, &c->msm_keys2, &c->msm_vals2, &c->msm_sort_tmp, &c->msm_bounds,
                                 &c->msm_buckets, &c->msm_chunks, &c->msm_windows, &c->msm_partials, &c->msm_flags,
                                 &c->st_coeffs, &c->msm_cnt, &c->msm_cnt2, &c->msm_ids, &c->msm_ids2, &c->msm_comb_pts,
-                                &c->msm_comb_lins, &c->msm_slice_recs, &c->ctab, &c->sg_sigs, &c->sg_pks})
+                                &c->msm_comb_lins, &c->msm_slice_recs, &c->msm_sbuf, &c->ctab, &c->sg_sigs, &c->sg_pks})
             sum += b->cap;
         return sum;
     };

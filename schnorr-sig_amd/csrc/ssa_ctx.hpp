@@ -98,6 +98,8 @@ struct ssa_ctx {
     // combined like the shards of a multi-GPU batch.  SSA_LANE_SLICE / SSA_MSM_SLICE override (tests force small ones).
     size_t lane_slice = (size_t)1 << 20, msm_slice = (size_t)1 << 23;
     DevBuf msm_slice_recs;        // one 24-word record per MSM slice
+    DevBuf msm_sbuf;              // the coefficients s_i between the two halves of the preparation (32 B per signature)
+    bool msm_overlap = true;      // the h-independent half of msm_k_prepare runs under ssa_k_hash (SSA_MSM_OVERLAP=0: off)
     unsigned msm_tree_group = 16; // chunk sums added per cooperating wave and tree level (SSA_MSM_TREE_GROUP: 2..64)
     // signing (ssa_sign.hip): the 4-bit comb table of the constant-time signer (98 KB, built at the first use) and the
     // intermediates of the keyed (130-byte) output

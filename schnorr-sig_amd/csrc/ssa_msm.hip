@@ -104,7 +104,12 @@ __global__ void __launch_bounds__(256)
 msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 *__restrict__ pk_inf,
               const u64 *__restrict__ h_in,
               const u8 *__restrict__ coeffs, u32 coeff_bytes, size_t n, MsmShape shp, u32 wa, u64 *__restrict__ points,
-              short *__restrict__ digits, u64 *__restrict__ partials, u32 *__restrict__ malformed) {
+              short *__restrict__ digits, u64 *__restrict__ partials, u32 *__restrict__ malformed,
+              u64 *__restrict__ s_out) {
+    // h_in == nullptr (round 5): everything that does not need the challenge scalars -- the checks, R's square root,
+    // the coefficient's digits, s_i e_i -- so that this kernel can run on a second stream UNDER ssa_k_hash (it fills the
+    // hash kernel's tail and its own); the coefficient s_i is left in s_out for msm_k_prepare_h, which writes the digits
+    // of s_i h_i once the hashes exist.
     __shared__ u64 red[256 * 4];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     sc256 se;
@@ -168,15 +173,20 @@ msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 
             }
             s = sc_neg_mod(s_abs);
         }
-        sc256 h;
-#pragma unroll
-        for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
-        const sc256 sh = sc_mul_mod(s, h);                             // hashes[i] *= scalars[i], :109-111
         if (ok) se = sc_mul_mod(s, e);                                 // s * e, :92-97
         P.y = f6_canon(f6_neg(P.y));                                   // k.0.neg(), :106
         st_aff_row(points + 12 * i, R);
         st_aff_row(points + 12 * (n + i), P);
-        (void)write_signed_digits(sh, shp.c, shp.windows, digits, 2 * n, n + i);
+        if (h_in) {
+            sc256 h;
+#pragma unroll
+            for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
+            const sc256 sh = sc_mul_mod(s, h);                         // hashes[i] *= scalars[i], :109-111
+            (void)write_signed_digits(sh, shp.c, shp.windows, digits, 2 * n, n + i);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_out[4 * i + k] = s.w[k];
+        }
     }
     // block reduction of s_i e_i mod q
 #pragma unroll
@@ -200,6 +210,21 @@ msm_k_prepare(const u8 *__restrict__ sigs, const u8 *__restrict__ pks, const u8 
 #pragma unroll
         for (int k = 0; k < 4; k++) partials[4 * blockIdx.x + k] = red[k];
     }
+}
+
+// the half of msm_k_prepare that needs the challenge scalars: the digits of s_i h_i for the point -P_i
+__global__ void __launch_bounds__(256)
+msm_k_prepare_h(const u64 *__restrict__ h_in, const u64 *__restrict__ s_in, size_t n, MsmShape shp,
+                short *__restrict__ digits) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sc256 s, h;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        s.w[k] = s_in[4 * i + k];
+        h.w[k] = h_in[4 * i + k];
+    }
+    (void)write_signed_digits(sc_mul_mod(s, h), shp.c, shp.windows, digits, 2 * n, n + i);   // hashes[i] *= scalars[i], :109-111
 }
 
 // ---- 2. grouping the items by bucket ------------------------------------------------------------------
@@ -1084,17 +1109,47 @@ static int msm_run_one(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks
         ctx->msm_partials.reserve((size_t)n_blocks * 32) || ctx->msm_flags.reserve(64))
         return SSA_ERR_HIP;
     HIP_TRY(hipMemsetAsync(ctx->msm_flags.p, 0, 64, ctx->stream));
-    // challenge scalars h_i with the kernel of the per-lane path
-    if (!d_h) {
-        if (int rc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) return rc;
+    int rc = 0;
+    if (!d_h && ctx->msm_overlap) {
+        // The challenge hashes are 62 % of this form and nothing but the digits of s_i h_i needs them: the rest of the
+        // preparation (R's square roots above all) runs on a second stream UNDER ssa_k_hash -- its waves fill the hash
+        // kernel's tail (the last wave of every SIMD alone, 0.35 ms) and the hash fills theirs --, ctx->stream joins it
+        // after the hash and writes the digits that were missing.
+        if (ctx->msm_sbuf.reserve(n * 32)) return SSA_ERR_HIP;
+        hipStream_t side = ctx->hash_stream[0];
+        HIP_TRY(hipEventRecord(ctx->pipe_start, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(side, ctx->pipe_start, 0));
+        hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, side, d_sigs, d_pks, d_pk_inf,
+                           (const u64 *)nullptr, d_coeffs, coeff_bytes, n, sh, wa, (u64 *)ctx->msm_points.p,
+                           (short *)ctx->msm_scalars.p, (u64 *)ctx->msm_partials.p, (u32 *)ctx->msm_flags.p,
+                           (u64 *)ctx->msm_sbuf.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ctx->hash_done[0], side));
+        if (int hrc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) {
+            (void)hipStreamSynchronize(side);
+            return hrc;
+        }
         d_h = (const u64 *)ctx->ws_h.p;
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->hash_done[0], 0));
+        rc = timed_launch(ctx, "msm_k_prepare", [&] {
+            hipLaunchKernelGGL(msm_k_prepare_h, dim3(n_blocks), dim3(256), 0, ctx->stream, d_h, (const u64 *)ctx->msm_sbuf.p,
+                               n, sh, (short *)ctx->msm_scalars.p);
+        });
+        if (rc) return rc;
+    } else {
+        // challenge scalars h_i with the kernel of the per-lane path
+        if (!d_h) {
+            if (int hrc = ssa_internal_hash_scalars(ctx, d_sigs, d_pks, d_msgs, d_msg_off, msg_stride, msg_len, n)) return hrc;
+            d_h = (const u64 *)ctx->ws_h.p;
+        }
+        rc = timed_launch(ctx, "msm_k_prepare", [&] {
+            hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, ctx->stream, d_sigs, d_pks, d_pk_inf,
+                               d_h, d_coeffs, coeff_bytes, n, sh, wa, (u64 *)ctx->msm_points.p,
+                               (short *)ctx->msm_scalars.p, (u64 *)ctx->msm_partials.p, (u32 *)ctx->msm_flags.p,
+                               (u64 *)nullptr);
+        });
+        if (rc) return rc;
     }
-    int rc = timed_launch(ctx, "msm_k_prepare", [&] {
-        hipLaunchKernelGGL(msm_k_prepare, dim3(n_blocks), dim3(256), 0, ctx->stream, d_sigs, d_pks, d_pk_inf,
-                           d_h, d_coeffs, coeff_bytes, n, sh, wa, (u64 *)ctx->msm_points.p,
-                           (short *)ctx->msm_scalars.p, (u64 *)ctx->msm_partials.p, (u32 *)ctx->msm_flags.p);
-    });
-    if (rc) return rc;
     rc = timed_launch(ctx, "msm_sort", [&] {
         hipLaunchKernelGGL(msm_k_hist, dim3(n_tiles), dim3(256), 0, ctx->stream, (const short *)ctx->msm_scalars.p, it, tmax,
                            (u32 *)ctx->msm_keys.p);
