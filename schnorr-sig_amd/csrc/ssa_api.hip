@@ -418,10 +418,15 @@ extern "C" int ssa_ctx_enable_timing(ssa_ctx *ctx, int on) {
 extern "C" int ssa_ctx_read_timing(ssa_ctx *ctx, const char *kernel, double *avg_ms, uint64_t *launches) {
     if (!ctx || !kernel) return SSA_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    auto it = ctx->timed.find(kernel);
     double total = 0;
     uint64_t cnt = 0;
-    if (it != ctx->timed.end()) {
+    // the context's own launches and, after calls of more than one slice, its twin's (whose launches overlap the
+    // context's: their event times are then not exclusive -- DESIGN.md section 5)
+    for (ssa_ctx *c : {ctx, ctx->twin}) {
+        if (!c) continue;
+        if (c != ctx) HIP_TRY(hipStreamSynchronize(c->stream));
+        auto it = c->timed.find(kernel);
+        if (it == c->timed.end()) continue;
         for (auto &t : it->second) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
@@ -431,7 +436,7 @@ extern "C" int ssa_ctx_read_timing(ssa_ctx *ctx, const char *kernel, double *avg
             (void)hipEventDestroy(t.start);
             (void)hipEventDestroy(t.stop);
         }
-        ctx->timed.erase(it);
+        c->timed.erase(it);
     }
     if (avg_ms) *avg_ms = cnt ? total / (double)cnt : 0.0;
     if (launches) *launches = cnt;
