@@ -87,7 +87,7 @@ def parse_args(argv=None):
                          "(config 4: 4194304); overrides --batch")
     ap.add_argument("--corrupt", type=float, default=0.0, help="fraction of corrupted signatures (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8192)
+    ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--skip-torsion-leg", action="store_true",
                     help="profiling runs: only the timed steps (no torsion / MSM / host-path / keyed legs)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N>1 weak run: skip the config-4 leg")
