@@ -195,8 +195,12 @@ struct PinnedRange {
     bool on = false;
     bool pin(const void *ptr, size_t bytes) {
         if (!ptr || bytes == 0) return true;
-        if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
+        const hipError_t err = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
+        if (err != hipSuccess) {
             (void)hipGetLastError();
+            if (ssa_debug_enabled())
+                std::fprintf(stderr, "[schnorr_sig_amd] hipHostRegister(%p, %zu) failed: %s -- staged copy instead\n", ptr, bytes,
+                             hipGetErrorString(err));
             return false;
         }
         p = const_cast<void *>(ptr);
