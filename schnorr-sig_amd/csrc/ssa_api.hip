@@ -188,6 +188,17 @@ extern "C" int ssa_ctx_create_ex(ssa_ctx **out, int device, const void *params, 
         const int v = std::atoi(tg);
         if (v >= 2 && v <= 64) ctx->msm_tree_group = (unsigned)v;
     }
+    if (const char *tpc = std::getenv("SSA_TAIL_PIECES")) {    // pieces of a tail group's work (0 / 1: no end game)
+        const int v = std::atoi(tpc);
+        if (v >= 0 && v <= VP_MAX) ctx->tail_pieces = (unsigned)v;
+    }
+    if (const char *tg = std::getenv("SSA_TAIL_GENS")) {       // tail groups, in generations of resident waves
+        const int v = std::atoi(tg);
+        if (v >= 1 && v <= 8) ctx->tail_gens = (unsigned)v;
+    }
+    if (const char *tu = std::getenv("SSA_TAIL_UNIFORM")) ctx->tail_uniform = std::atoi(tu) != 0;
+    if (const char *tm = std::getenv("SSA_TAIL_MIN_MAIN")) ctx->tail_min_main = (unsigned)std::atoi(tm);
+    if (const char *tw = std::getenv("SSA_TAIL_WAVES")) ctx->tail_waves_override = (unsigned)std::atoi(tw);   // tests: a small "generation"
     if (const char *ts = std::getenv("SSA_TWO_STREAMS")) ctx->two_streams = std::atoi(ts) != 0;
     if (const char *mo = std::getenv("SSA_MSM_OVERLAP")) ctx->msm_overlap = std::atoi(mo) != 0;
     if (const char *pc = std::getenv("SSA_PIPELINE_CHUNKS")) {
@@ -216,6 +227,15 @@ extern "C" int ssa_ctx_create_ex(ssa_ctx **out, int device, const void *params, 
             return SSA_ERR_HIP;
         }
     ctx->stream = ctx->own_stream;
+    {   // the waves of ssa_k_verify that are resident at once: the size of its end game
+        hipDeviceProp_t prop;
+        int occ = 0;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ssa_k_verify, 256, 0) == hipSuccess && occ > 0)
+            ctx->verify_waves = (unsigned)prop.multiProcessorCount * (unsigned)occ * 4u;
+        (void)hipGetLastError();
+        if (ctx->tail_waves_override) ctx->verify_waves = ctx->tail_waves_override;
+    }
     if (hipMalloc((void **)&ctx->d_params, sizeof(DevParams)) != hipSuccess) {
         ssa_ctx_destroy(ctx);
         return SSA_ERR_HIP;
@@ -297,6 +317,11 @@ ssa_ctx *ssa_internal_twin(ssa_ctx *ctx) {
         t->pipeline_chunks = ctx->pipeline_chunks;
         t->pipeline_min_n = ctx->pipeline_min_n;
         t->verify_block = ctx->verify_block;
+        t->tail_pieces = ctx->tail_pieces;
+        t->tail_gens = ctx->tail_gens;
+        t->tail_uniform = ctx->tail_uniform;
+        t->tail_min_main = ctx->tail_min_main;
+        t->verify_waves = ctx->verify_waves;
         ctx->twin = t;
     }
     ctx->twin->timing = ctx->timing;
@@ -328,7 +353,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->msm_scalars, &ctx->msm_keys, &ctx->msm_vals, &ctx->msm_keys2, &ctx->msm_vals2,
                       &ctx->msm_sort_tmp, &ctx->msm_bounds, &ctx->msm_buckets, &ctx->msm_chunks, &ctx->msm_windows,
                       &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
-                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->msm_sbuf, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks})
+                      &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->msm_sbuf, &ctx->tail_done, &ctx->tail_park, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks})
         b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     gtab_release(ctx->gtab_share);
@@ -360,7 +385,7 @@ extern "C" int ssa_ctx_info(const ssa_ctx *ctx, uint64_t out[8]) {
                                 &c->msm_keys, &c->msm_vals, &c->msm_keys2, &c->msm_vals2, &c->msm_sort_tmp, &c->msm_bounds,
                                 &c->msm_buckets, &c->msm_chunks, &c->msm_windows, &c->msm_partials, &c->msm_flags,
                                 &c->st_coeffs, &c->msm_cnt, &c->msm_cnt2, &c->msm_ids, &c->msm_ids2, &c->msm_comb_pts,
-                                &c->msm_comb_lins, &c->msm_slice_recs, &c->msm_sbuf, &c->ctab, &c->sg_sigs, &c->sg_pks})
+                                &c->msm_comb_lins, &c->msm_slice_recs, &c->msm_sbuf, &c->tail_done, &c->tail_park, &c->ctab, &c->sg_sigs, &c->sg_pks})
             sum += b->cap;
         return sum;
     };
@@ -518,6 +543,69 @@ static inline MsgView msg_slice(const MsgView &mv, size_t lo) {
     return s;
 }
 
+// The end game of an ssa_k_verify launch over cnt lanes: which groups run in pieces, where their work is cut.  The cuts
+// follow instruction counts (a doubling 2642 VALU instructions, a mixed addition 3738; the table build ~57 k in front of
+// the first pass, the comb for G and the comparison ~45 k behind the last): the first piece is half of a lane's work, the
+// next a quarter, ... the last two equal (SSA_TAIL_UNIFORM=1: equal pieces); a piece never spans the two passes of
+// SSA_FLAG_CHECK_TORSION.
+static TailPlan tail_plan(const ssa_ctx *ctx, size_t cnt, uint32_t flags) {
+    TailPlan tp{};
+    const bool torsion = (flags & SSA_FLAG_CHECK_TORSION) != 0;
+    tp.whole[0] = 0u | 2u | 4u | ((u32)LADDER_STEPS_Q << 16);
+    tp.whole[1] = 1u | 2u | 4u | ((u32)LADDER_STEPS << 16);
+    const u32 n_groups = (u32)((cnt + 63) / 64);
+    const unsigned cap = torsion ? (unsigned)VP_MAX - 1u : (unsigned)VP_MAX;      // (the pass boundary is one more cut)
+    const unsigned want = ctx->tail_pieces < cap ? ctx->tail_pieces : cap;
+    const u32 tail0 = ctx->tail_gens * ctx->verify_waves;
+    if (want < 2 || ctx->verify_block != 256 || tail0 == 0 || n_groups < tail0 + ctx->tail_min_main * ctx->verify_waves) return tp;
+    const u32 main_groups = ((n_groups - tail0) / 4u) * 4u;
+    tp.main_blocks = main_groups / 4u;
+    tp.tail_groups = ((n_groups - main_groups + 3u) / 4u) * 4u;
+    // the lane's work as one sequence of steps: [pass 0 windows] [pass 1 windows], with the table build in front and the
+    // comb + comparison behind
+    const double DBL = 2642.0, ADD = 3738.0, TABLE = 57000.0, TAIL = 45000.0;
+    struct Step { int pass, it; double cost; };
+    std::vector<Step> steps;
+    for (int pass = torsion ? 0 : 1; pass < 2; pass++)
+        for (int it = 0; it < (pass == 0 ? LADDER_STEPS_Q : LADDER_STEPS); it++)
+            steps.push_back({pass, it, (pass == 0 ? (double)QNAF_GAP[it + 1] : 5.0) * DBL + ADD});
+    double total = TABLE + TAIL;
+    for (const Step &st : steps) total += st.cost;
+    // cumulative targets of the pieces
+    std::vector<double> target;
+    double frac = 0.0, f = 0.5;
+    for (unsigned k = 0; k + 1 < want; k++) {
+        frac += ctx->tail_uniform ? 1.0 / (double)want : f;
+        if (k + 2 < want) f *= 0.5;
+        target.push_back(total * frac);
+    }
+    // cut in front of the step that would cross a target (and between the passes, always)
+    std::vector<std::pair<size_t, size_t>> pieces;
+    size_t cur = 0, tix = 0;
+    double acc = TABLE;
+    for (size_t idx = 0; idx < steps.size(); idx++) {
+        bool cut = false;
+        if (idx > cur) {
+            if (steps[idx].pass != steps[idx - 1].pass) cut = true;
+            else if (tix < target.size() && acc + steps[idx].cost * 0.5 >= target[tix]) cut = true;
+        }
+        if (cut) {
+            pieces.push_back({cur, idx});
+            cur = idx;
+        }
+        while (tix < target.size() && acc + steps[idx].cost * 0.5 >= target[tix]) tix++;     // targets reached
+        acc += steps[idx].cost;
+    }
+    pieces.push_back({cur, steps.size()});
+    if (pieces.size() < 2 || pieces.size() > (size_t)VP_MAX) return tp;        // (n_pieces stays 0: no end game)
+    for (const auto &pc : pieces) {
+        const int pass = steps[pc.first].pass, lo = steps[pc.first].it, hi = steps[pc.second - 1].it + 1;
+        const int n_steps = pass == 0 ? LADDER_STEPS_Q : LADDER_STEPS;
+        tp.ph[tp.n_pieces++] = (u32)pass | (lo == 0 ? 2u : 0u) | (hi == n_steps ? 4u : 0u) | ((u32)lo << 8) | ((u32)hi << 16);
+    }
+    return tp;
+}
+
 // ssa_k_verify over n lanes whose challenge scalars are in d_h, in slices of at most ctx->lane_slice lanes: the 4 KB
 // per-lane table workspace never exceeds one slice (the caller has reserved it).  *d_fail is added to.
 static int verify_slices(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_inf,
@@ -525,11 +613,20 @@ static int verify_slices(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_p
     const size_t slice = ctx->lane_slice < n ? ctx->lane_slice : n;
     for (size_t lo = 0; lo < n; lo += slice) {
         const size_t cnt = n - lo < slice ? n - lo : slice;
+        const TailPlan tp = tail_plan(ctx, cnt, flags);
+        unsigned blocks = grid_for(cnt, ctx->verify_block);
+        if (tp.n_pieces) {
+            if (ctx->tail_done.reserve((size_t)tp.tail_groups * sizeof(u32)) ||
+                ctx->tail_park.reserve((size_t)tp.tail_groups * PARK_WORDS * 64 * sizeof(u64)))
+                return SSA_ERR_HIP;
+            HIP_TRY(hipMemsetAsync(ctx->tail_done.p, 0, (size_t)tp.tail_groups * sizeof(u32), ctx->stream));
+            blocks = tail_grid_blocks(tp);
+        }
         int rc = timed_launch(ctx, "ssa_k_verify", [&] {
-            hipLaunchKernelGGL(ssa_k_verify, dim3(grid_for(cnt, ctx->verify_block)), dim3(ctx->verify_block), 0,
+            hipLaunchKernelGGL(ssa_k_verify, dim3(blocks), dim3(ctx->verify_block), 0,
                                ctx->stream, d_sigs + 81 * lo, d_pks + 96 * lo, d_pk_inf ? d_pk_inf + lo : nullptr,
                                d_h + 4 * lo, (const u64 *)ctx->d_gtab, (u64 *)ctx->ws_tab.p, cnt, flags,
-                               d_status_out + lo, d_fail);
+                               d_status_out + lo, d_fail, tp, (u32 *)ctx->tail_done.p, (u64 *)ctx->tail_park.p);
         });
         if (rc) return rc;
     }

@@ -106,6 +106,15 @@ struct ssa_ctx {
     DevBuf ctab, sg_sigs, sg_pks;
     bool ctab_ready = false;
     unsigned verify_block = 256;  // threads per block of ssa_k_verify (SSA_VERIFY_BLOCK overrides: 64/128/256)
+    // the end game of ssa_k_verify (ssa_kernels.hpp "The end game of a launch"): the last generation of lanes runs in
+    // tail_pieces pieces per ladder pass, only the last of which stand at the end of the grid
+    unsigned verify_waves = 0;    // waves of ssa_k_verify resident at once on this device (occupancy x CUs x 4)
+    unsigned tail_pieces = 5;     // SSA_TAIL_PIECES (0 or 1: off); launches of less than one generation have none
+    unsigned tail_gens = 1;       // SSA_TAIL_GENS: tail groups, in generations of resident waves
+    bool tail_uniform = false;    // SSA_TAIL_UNIFORM=1: equal pieces instead of 1/2, 1/4, 1/8, ...
+    unsigned tail_min_main = 0;   // SSA_TAIL_MIN_MAIN: generations of ordinary workgroups a launch must have beside its tail
+    unsigned tail_waves_override = 0;   // SSA_TAIL_WAVES: the tests' small "generation" (the end game on batches of thousands)
+    DevBuf tail_done, tail_park;  // per tail group: finished pieces; parked accumulators + status (152 B per lane)
     std::map<std::string, std::vector<TimedLaunch>> timed;
     std::vector<struct ssa_keyset *> keysets;   // live key sets of this context (orphaned, not leaked, by ssa_ctx_destroy)
 };

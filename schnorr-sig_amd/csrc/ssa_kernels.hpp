@@ -433,10 +433,12 @@ SSA_DEV void build_ptab(u64 *__restrict__ tab, const aff &p, bool p_inf) {
 // every lane in lock-step: 250 doublings + 51 additions (round 3, 4-bit windows over 1P..8P: 252 + 63).
 // order_q: [q]P for the subgroup check (is_torsion_free, src/signature.rs:182) -- the scalar is a constant, so its
 // schedule is chosen offline: the width-5 NAF of q (qnaf.inc, tools/gen_qnaf.py), 43 additions and 255 doublings with a
-// variable number of doublings per window (k is ignored).  Same loop, same window statement: the
+// variable number of doublings per window (kr is ignored).  Same loop, same window statement: the
 // ladder body exists once in the code.
-SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q = false) {
-    const sc256 kr = sc_recode_offset5(k);
+// The ladder comes in two functions so that the pieces of ssa_k_verify's end game can stop after any window and park the
+// accumulator: ladder_init picks the top digit, ladder_steps runs the windows [lo, hi).
+constexpr int LADDER_STEPS = 50, LADDER_STEPS_Q = QNAF_LEN - 1;
+SSA_DEV jac ladder_init(const u64 *__restrict__ tab, const sc256 &kr, bool order_q) {
     jac acc = jac_identity();
     const u32 top = order_q ? (u32)QNAF_DIGIT[0] : sc_top5(kr);   // in [0, 32]
     if (top != 0) {
@@ -444,9 +446,11 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q =
         if (!(f6_is_zero(p.x) && f6_is_zero(p.y))) acc = jac_from_aff(p);
         if (top > 16u) acc = jac_madd_fast(acc, ld_aff(tab + (top - 17u) * PTAB_ENTRY_U64));   // 16P + (top - 16)P
     }
-    const int steps = order_q ? QNAF_LEN - 1 : 50;
+    return acc;
+}
+SSA_DEV jac ladder_steps(jac acc, const u64 *__restrict__ tab, const sc256 &kr, bool order_q, int lo, int hi) {
 #pragma unroll 1
-    for (int it = 0; it < steps; it++) {
+    for (int it = lo; it < hi; it++) {
         int digit;
         u32 gap;
         if (order_q) {
@@ -477,6 +481,10 @@ SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q =
 #endif
     }
     return acc;
+}
+SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q = false) {
+    const sc256 kr = sc_recode_offset5(k);
+    return ladder_steps(ladder_init(tab, kr, order_q), tab, kr, order_q, 0, order_q ? LADDER_STEPS_Q : LADDER_STEPS);
 }
 
 // acc += [e]G from the comb table: one mixed addition per non-zero window of e (the table's own geometry)
@@ -518,25 +526,123 @@ SSA_FN bool x_on_curve(const fp6 &x) {
 
 constexpr u32 VF_CHECK_TORSION = 1u, VF_SIG_FLAG_BYTE = 8u;
 #ifdef SSA_WAVE_TIMES
-constexpr size_t SSA_WAVE_TIMES_MAX = 1u << 15;
+constexpr size_t SSA_WAVE_TIMES_MAX = 1u << 16;
 __device__ unsigned long long g_wave_times[3 * SSA_WAVE_TIMES_MAX];
 #endif
+
+// ------------------------------------------------------------------------------------------
+// The end game of a launch (round 5).  A launch of one workgroup per 256 lanes ends with every SIMD finishing its last
+// wave alone -- the sequencer serves the older wave of a SIMD first (76 % of the issue slots), so the younger one has
+// most of its 3.2 ms ahead of it when its neighbour leaves, and a lone wave issues every 6.2 cycles instead of 4: 0.65 ms
+// of a 26.6 ms launch (profiles/r05/job_sched_ab.txt).  What the scheduler experiment of this round showed is that SHORT
+// last jobs cure it and that persistent waves and jobs in pieces everywhere cost more than they bring.  So, statically:
+// the LAST generation of lanes (the tail groups: as many 64-lane groups as there are resident waves) is cut into pieces at
+// window boundaries of the ladder -- the first half of the work, then a quarter, an eighth, ... -- ; the workgroups of the
+// first pieces open the grid, where they are ordinary waves among ordinary waves, and all the other pieces close it,
+// piece-major: the kernel ends with half a generation of work in waves that get shorter and shorter, which is what it takes
+// to fill the staircase the SIMDs' slots free up in (they end a generation 2 ms apart).  Between two pieces a lane's
+// accumulator and status are parked in HBM, lane-interleaved; the lanes' tables stay where they are.  Everything else is
+// the launch it always was: no counter, no persistent wave.
+//   grid: [piece 0][ordinary workgroups][piece 1][piece 2] ... [piece P-1]; a piece workgroup runs four tail groups.
+// Workgroups are dispatched in grid order, so piece p - 1 of a group was dispatched before its piece p (a whole launch
+// before, for piece 0); correctness does not rest on that: done[g] counts the finished pieces (release after the parked
+// state and, for piece 0, the tables are written; acquire before they are read: the XCDs' L2s are not coherent with each
+// other), and a wave whose predecessor has not finished sleeps on the flag -- the predecessor's workgroup precedes it in
+// the grid and is resident or done.
+constexpr int VP_MAX = 8;
+struct TailPlan {
+    u32 n_pieces;            // 0: no end game (every workgroup is an ordinary one)
+    u32 tail_groups;         // K: 64-lane groups at the end of the batch that run in pieces (a multiple of 4)
+    u32 main_blocks;         // ordinary workgroups (256 lanes each): lanes [0, 256 * main_blocks)
+    u32 ph[VP_MAX];          // piece p: pass | first-of-pass << 1 | last-of-pass << 2 | it_lo << 8 | it_hi << 16
+    u32 whole[2];            // the same descriptor for a whole pass 0 / pass 1 (ordinary workgroups)
+};
+__host__ __device__ inline u32 tail_grid_blocks(const TailPlan &tp) { return tp.main_blocks + tp.n_pieces * (tp.tail_groups / 4u); }
+struct BlockRole {
+    u32 piece;               // piece index, or 0xffffffff for an ordinary workgroup
+    u32 index;               // ordinary: its number among the ordinary workgroups; piece: its number among the piece's
+};
+SSA_DEV BlockRole tail_role(const TailPlan &tp, u32 blk) {
+    // grid: [piece 0 of the tail groups][the ordinary workgroups][piece 1][piece 2] ... [piece P-1]
+    BlockRole r;
+    r.piece = 0xffffffffu;
+    r.index = blk;
+    if (tp.n_pieces == 0) return r;
+    const u32 pb = tp.tail_groups / 4u;
+    if (blk < pb) {
+        r.piece = 0;
+        return r;
+    }
+    if (blk < pb + tp.main_blocks) {
+        r.index = blk - pb;
+        return r;
+    }
+    const u32 q = blk - pb - tp.main_blocks;
+    r.piece = 1u + q / pb;
+    r.index = q - (r.piece - 1u) * pb;
+    return r;
+}
+constexpr int PARK_WORDS = 19;   // X, Y, Z of a lane's accumulator and its status word; word w of lane l of tail group e
+                                 // at park[(e * PARK_WORDS + w) * 64 + l]
+// the parked state is written with agent-scope stores (write-through past the XCD's L2)
+SSA_DEV void st_shared(u64 *__restrict__ p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SSA_DEV void park_store(u64 *__restrict__ pk, const jac &r) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        st_shared(pk + k * 64, r.X.c[k]);
+        st_shared(pk + (6 + k) * 64, r.Y.c[k]);
+        st_shared(pk + (12 + k) * 64, r.Z.c[k]);
+    }
+}
+SSA_DEV jac park_load(const u64 *__restrict__ pk) {
+    jac r;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        r.X.c[k] = pk[k * 64];
+        r.Y.c[k] = pk[(6 + k) * 64];
+        r.Z.c[k] = pk[(12 + k) * 64];
+    }
+    return r;
+}
 
 #ifndef SSA_NO_KERNELS
 __global__ void __launch_bounds__(256, 2)
 ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
              const u8 *__restrict__ pk_inf, const u64 *__restrict__ h_in,
              const u64 *__restrict__ gtab, u64 *__restrict__ ws_tab, size_t n, u32 flags,
-             u8 *__restrict__ status_out, unsigned long long *__restrict__ n_fail) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 status = ST_OK;
+             u8 *__restrict__ status_out, unsigned long long *__restrict__ n_fail,
+             TailPlan tp, u32 *__restrict__ done, u64 *__restrict__ park) {
 #ifdef SSA_WAVE_TIMES       // diagnostic build only (tools/wave_times.py): when and where every wave of the kernel ran
     const unsigned long long wt0 = wall_clock64();
 #endif
-    if (i < n) {
+    // which lanes, which pieces: an ordinary workgroup runs its 256 lanes from start to end; a piece workgroup runs one
+    // piece of four tail groups (wave w: tail group 4 * index + w).  (Measured and dropped: the closing waves pulling
+    // their (piece, group) jobs from a counter until it runs dry, so that the faster XCDs take more -- the XCDs then do
+    // finish together, 0.4 ms LATER: profiles/r05/end_game_ab.txt.)
+    const BlockRole role = tail_role(tp, blockIdx.x);
+    const u32 lane = threadIdx.x & 63u;
+    const bool in_piece = role.piece != 0xffffffffu;
+    const u32 p_lo = in_piece ? role.piece : 0u;
+    const u32 eg = in_piece ? 4u * role.index + (threadIdx.x >> 6) : 0u;                  // tail group (pieces only)
+    const size_t i = in_piece ? ((size_t)tp.main_blocks * 256u + (size_t)eg * 64u + lane)
+                              : ((size_t)role.index * blockDim.x + threadIdx.x);
+    const bool runs_last = !in_piece || p_lo + 1u == tp.n_pieces;                         // this wave delivers the status
+    const bool in = i < n;
+    u64 *pk = park + ((size_t)eg * PARK_WORDS) * 64 + lane;
+    u64 *tab = ws_tab + i * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64);
+    u32 status = ST_OK;
+    bool ok_sig = true;
+    jac r = jac_identity();
+    if (in_piece && p_lo > 0) {
+        while (__hip_atomic_load(done + eg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < p_lo) __builtin_amdgcn_s_sleep(64);
+        const u64 sw = pk[18 * 64];
+        status = (u32)(sw & 0xffu);
+        ok_sig = ((sw >> 8) & 1u) != 0;
+        if (in && status == ST_OK && !(tp.ph[p_lo] & 2u)) r = park_load(pk);              // (a pass's first piece starts afresh)
+    } else if (in) {
         // check order of the reference (src/signature.rs:181-205): the key first (subgroup check, :182),
         // then the signature's x (Fp6::from_bytes(..).unwrap() panics at :186 -> SSA_MALFORMED)
-        bool ok_sig = true, ok = true;
+        bool ok = true;
         const fp6 xs = ld_fp6(sigs + 81 * i, ok_sig);
         const sc256 e = ld_sc(sigs + 81 * i + 49);
         ok_sig = ok_sig && !sc_geq_q(e);
@@ -547,30 +653,44 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
         P.y = ld_fp6(pks + 96 * i + 48, ok);
         const bool inf = pk_inf && pk_inf[i];
         if (ok && !inf) ok = aff_on_curve(P);
-        if (!ok) {
-            status = ST_MALFORMED;
-        } else {
-            u64 *tab = ws_tab + i * (size_t)(PTAB_ENTRIES * PTAB_ENTRY_U64);
-            build_ptab(tab, P, inf);
-            // pass 0 (only with SSA_FLAG_CHECK_TORSION): [q]P == O, is_torsion_free, :182-184
-            // pass 1: [h]P.  One rolled loop so that the ladder body exists once in the code.
-            sc256 h;
+        if (!ok) status = ST_MALFORMED;
+        else build_ptab(tab, P, inf);
+    }
+    // pass 0 (only with SSA_FLAG_CHECK_TORSION): [q]P == O, is_torsion_free, :182-184 -- the offline schedule of the
+    // constant q; pass 1: [h]P.  One rolled loop (ladder_steps) so that the ladder body exists once in the code.
+    if (in && status == ST_OK) {
+        sc256 h;
 #pragma unroll
-            for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
-            jac r = jac_identity();
+        for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
+        const sc256 kr = sc_recode_offset5(h);
+        // the descriptors this wave runs: one piece, or the whole passes (pass 0 only with the subgroup check)
+        const u32 d_lo = in_piece ? p_lo : ((flags & VF_CHECK_TORSION) ? 0u : 1u);
+        const u32 d_hi = in_piece ? p_lo + 1u : 2u;
 #pragma unroll 1
-            for (int pass = (flags & VF_CHECK_TORSION) ? 0 : 1; pass < 2; pass++) {
-                if (pass == 1 && !ok_sig) {
+        for (u32 k = d_lo; k < d_hi; k++) {
+            const u32 d = in_piece ? tp.ph[k] : tp.whole[k];
+            const bool pass_q = (d & 1u) == 0, first = (d & 2u) != 0, last = (d & 4u) != 0;
+            if (first) {
+                if (!pass_q && !ok_sig) {
                     status = ST_MALFORMED;
                     break;
                 }
-                r = mul_ptab(tab, h, pass == 0);        // pass 0: the offline schedule of the constant q
-                if (pass == 0 && !jac_is_identity(r)) {
-                    status = ST_INVALID_PK;
-                    break;
-                }
+                r = ladder_init(tab, kr, pass_q);
             }
+            r = ladder_steps(r, tab, kr, pass_q, (int)((d >> 8) & 0xffu), (int)((d >> 16) & 0xffu));
+            if (last && pass_q && !jac_is_identity(r)) {
+                status = ST_INVALID_PK;
+                break;
+            }
+        }
+    }
+    if (runs_last) {
+        if (in) {
             if (status == ST_OK) {
+                bool okx = true;
+                const fp6 xs = ld_fp6(sigs + 81 * i, okx);
+                const sc256 e = ld_sc(sigs + 81 * i + 49);
+                const u32 fbyte = sigs[81 * i + 48];
                 r = add_base_mul(r, gtab, e);               // + [e]G, :196-198
                 // r.get_x() == x_felt (:200): X == x * Z^2; the identity's x is taken as 0
                 bool eq;
@@ -591,15 +711,27 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
                 }
                 status = eq ? ST_OK : (ok_sig ? ST_INVALID_SIG : ST_MALFORMED);
             }
+            status_out[i] = (u8)status;
         }
-        status_out[i] = (u8)status;
+        // aggregate verdict: one ballot + one atomic per wave
+        const unsigned long long bad = __ballot(status != ST_OK);
+        if (lane == 0 && bad) atomicAdd(n_fail, (unsigned long long)__popcll(bad));
+    } else {
+        // park the lane and publish the piece: the first piece has written the lanes' tables with ordinary stores and
+        // needs the XCD's L2 written back (release at agent scope); later pieces wrote only the parked words, which are
+        // agent-scope stores already, and the flag just has to follow them
+        if (in && status == ST_OK) park_store(pk, r);
+        st_shared(pk + 18 * 64, (u64)status | ((u64)(ok_sig ? 1u : 0u) << 8));
+        if (p_lo == 0) {
+            __hip_atomic_store(done + eg, p_lo + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(done + eg, p_lo + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    // aggregate verdict: one ballot + one atomic per wave
-    const unsigned long long bad = __ballot(status != ST_OK);
-    if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(n_fail, (unsigned long long)__popcll(bad));
 #ifdef SSA_WAVE_TIMES
-    if ((threadIdx.x & 63u) == 0) {
-        const size_t w = i / 64;
+    if (lane == 0) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
         if (w < SSA_WAVE_TIMES_MAX) {
             g_wave_times[3 * w] = wt0;
             g_wave_times[3 * w + 1] = wall_clock64();

@@ -275,3 +275,65 @@ def test_pubkey_many_is_one_base_multiplication(engine, oracle):
     assert kp.public_key.affine == bytes(pks[9]) and ssa.PublicKey.from_private(sk, engine).affine == bytes(pks[9])
     sig = kp.sign(b"round five", lambda k: bytes(rng.integers(0, 256, size=k, dtype=np.uint8)), engine)
     assert sig.verify(b"round five", kp.public_key, engine) is None
+
+
+# ---------------------------------------------------------------- the end game of ssa_k_verify
+def _tail_engine(pieces, waves=32, gens=1, uniform=False):
+    """an engine whose "generation" is `waves` waves, so that batches of thousands run the end game: the last generation of
+    lanes in `pieces` pieces with the accumulator parked in between (read at ssa_ctx_create)"""
+    import schnorr_sig_amd as ssa
+    env = {"SSA_TAIL_WAVES": str(waves), "SSA_TAIL_PIECES": str(pieces), "SSA_TAIL_GENS": str(gens),
+           "SSA_TAIL_UNIFORM": "1" if uniform else "0"}
+    os.environ.update(env)
+    try:
+        return ssa.Engine(0)
+    finally:
+        for k in env:
+            del os.environ[k]
+
+
+@pytest.mark.parametrize("pieces,gens,uniform", [(2, 1, False), (3, 1, False), (5, 2, False), (8, 1, False), (4, 1, True), (7, 3, True)])
+def test_end_game_pieces_equal_whole_lanes(engine, oracle, pieces, gens, uniform):
+    """ssa_k_verify with its last generation(s) of lanes cut into pieces (accumulator and status parked between them, flags
+    with release / acquire) gives the status vector of the plain launch and of the oracle: every corruption class, malformed
+    inputs, identity keys and the non-subgroup fixture INSIDE the tail groups, subgroup check (two passes: a piece never
+    spans them) and flag byte on and off, a ragged last group"""
+    rng = np.random.default_rng(5400 + pieces)
+    waves = 32
+    n = (2 + gens) * waves * 64 + 1000 + 37                 # tail = the last gens * 2048 lanes (+ the ragged remainder)
+    sigs, pks, msgs = honest(engine, rng, n)
+    sigs, pks, msgs, inf, bad = _spoil(rng, sigs, pks, msgs, 160)
+    tail0 = n - gens * waves * 64 - 500
+    t = np.arange(tail0, n)
+    rng.shuffle(t)
+    sigs[t[0], 49] ^= 1                                       # inside the tail: e
+    msgs[t[1], 3] ^= 8                                        # message
+    pks[t[2]] = pks[t[3]]                                     # someone else's key
+    pks[t[4]] = _fixture_key()                                # not in the prime subgroup
+    sigs[t[5], :8] = 0xFF                                     # limb >= p: malformed signature
+    pks[t[6], 90:96] = 0xFF                                   # malformed key
+    inf[t[7]] = 1                                             # identity key
+    sigs[t[8], 48] ^= 0x40                                    # the other root of R (flag-byte semantics only)
+    sigs[t[9], 48] |= 2                                       # undecodable flag byte
+    sigs[t[10], 49:] = np.frombuffer(Q.to_bytes(32, "little"), np.uint8)   # e = q
+    eng = _tail_engine(pieces, waves, gens, uniform)
+    try:
+        for torsion in (False, True):
+            for fb in (False, True):
+                ref, nf_ref = engine.verify_many(sigs, pks, msgs, check_torsion=torsion, pk_inf=inf, mode="lane", sig_flag_byte=fb)
+                got, nf = eng.verify_many(sigs, pks, msgs, check_torsion=torsion, pk_inf=inf, mode="lane", sig_flag_byte=fb)
+                assert nf == nf_ref and (got == ref).all(), (torsion, fb, np.nonzero(got != ref)[0][:10])
+                samp = np.unique(np.concatenate([bad, t[:40], np.arange(0, n, 97), [n - 1]]))
+                exp = oracle.verify_many(sigs[samp], pks[samp], msgs[samp], check_torsion=torsion, pk_inf=inf[samp],
+                                         sig_flag_byte=fb)
+                assert (got[samp] == exp).all()
+            assert got[t[4]] == (1 if torsion else 2) and got[t[5]] == 3 and got[t[6]] == 3 and got[t[9]] == 3
+        # the same call again (flags and parked state are reset per launch), and a batch too small for an end game
+        got2, _ = eng.verify_many(sigs, pks, msgs, check_torsion=True, pk_inf=inf, mode="lane", sig_flag_byte=True)
+        assert (got2 == got).all()
+        small = slice(0, 3 * waves * 64 - 1)
+        a, _ = eng.verify_many(sigs[small], pks[small], msgs[small], check_torsion=True, pk_inf=inf[small], mode="lane")
+        b, _ = engine.verify_many(sigs[small], pks[small], msgs[small], check_torsion=True, pk_inf=inf[small], mode="lane")
+        assert (a == b).all()
+    finally:
+        eng.close()

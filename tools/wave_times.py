@@ -26,9 +26,13 @@ def main():
                                check_torsion=False, sig_flag_byte=True)
         eng.sync()
     lib = C.CDLL(os.environ["SSA_LIB"])
-    nw = min(n // 64, 1 << 15)
-    buf = np.zeros((nw, 3), dtype=np.uint64)
-    assert lib.ssa_debug_wave_times(buf.ctypes.data_as(C.c_void_p), C.c_size_t(nw)) == 0
+    cap = 1 << 16
+    raw = np.zeros((cap, 3), dtype=np.uint64)
+    assert lib.ssa_debug_wave_times(raw.ctypes.data_as(C.c_void_p), C.c_size_t(cap)) == 0
+    # the waves of the LAST launch (the end game adds piece workgroups to the grid: more waves than n / 64)
+    keep = (raw[:, 1] != 0) & (raw[:, 0] + np.uint64(20_000_000) >= raw[:, 1].max())
+    buf = raw[keep]
+    nw = len(buf)
     if len(sys.argv) > 2:
         np.save(sys.argv[2], buf)
     t0 = buf[:, 0].min()
@@ -51,6 +55,13 @@ def main():
         print("  XCC %d: %5d waves, duration mean %.1f us, last end %.1f us" % (x, sel.sum(), dur[sel].mean(), en[sel].max()))
     # busy-slot integral: how much of (span x capacity) is covered by waves
     print("  sum of wave durations / (span x %d slots) = %.4f" % (cap, dur.sum() / (en.max() * cap)))
+    short = dur < 0.6 * np.median(dur)
+    if short.any():
+        print("  %d short waves (pieces of the end game): duration mean %.1f us; %d of them end in the last %.0f us"
+              % (short.sum(), dur[short].mean(), int((short & (en > en.max() - 1500)).sum()), 1500))
+    last = order[-cap:]
+    print("  the last %d waves to start: starts %.1f .. %.1f us, ends %.1f .. %.1f us" % (len(last), st[last].min(), st[last].max(),
+                                                                                        en[last].min(), en[last].max()))
     cu = (hw >> 8) & 0xf
     se = (hw >> 13) & 0x7
     print("  hw id fields seen: cu %s se %s" % (sorted(set(cu.tolist())), sorted(set(se.tolist()))))
