@@ -198,6 +198,7 @@ extern "C" int ssa_ctx_create_ex(ssa_ctx **out, int device, const void *params, 
     }
     if (const char *tu = std::getenv("SSA_TAIL_UNIFORM")) ctx->tail_uniform = std::atoi(tu) != 0;
     if (const char *tm = std::getenv("SSA_TAIL_MIN_MAIN")) ctx->tail_min_main = (unsigned)std::atoi(tm);
+    if (const char *tr = std::getenv("SSA_TAIL_REVERSED")) ctx->tail_reversed = std::atoi(tr) != 0;
     if (const char *tw = std::getenv("SSA_TAIL_WAVES")) ctx->tail_waves_override = (unsigned)std::atoi(tw);   // tests: a small "generation"
     if (const char *ts = std::getenv("SSA_TWO_STREAMS")) ctx->two_streams = std::atoi(ts) != 0;
     if (const char *mo = std::getenv("SSA_MSM_OVERLAP")) ctx->msm_overlap = std::atoi(mo) != 0;
@@ -321,6 +322,7 @@ ssa_ctx *ssa_internal_twin(ssa_ctx *ctx) {
         t->tail_gens = ctx->tail_gens;
         t->tail_uniform = ctx->tail_uniform;
         t->tail_min_main = ctx->tail_min_main;
+        t->tail_reversed = ctx->tail_reversed;
         t->verify_waves = ctx->verify_waves;
         ctx->twin = t;
     }
@@ -603,6 +605,7 @@ static TailPlan tail_plan(const ssa_ctx *ctx, size_t cnt, uint32_t flags) {
         const int n_steps = pass == 0 ? LADDER_STEPS_Q : LADDER_STEPS;
         tp.ph[tp.n_pieces++] = (u32)pass | (lo == 0 ? 2u : 0u) | (hi == n_steps ? 4u : 0u) | ((u32)lo << 8) | ((u32)hi << 16);
     }
+    tp.reversed = ctx->tail_reversed ? 1u : 0u;
     return tp;
 }
 
@@ -616,10 +619,10 @@ static int verify_slices(ssa_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_p
         const TailPlan tp = tail_plan(ctx, cnt, flags);
         unsigned blocks = grid_for(cnt, ctx->verify_block);
         if (tp.n_pieces) {
-            if (ctx->tail_done.reserve((size_t)tp.tail_groups * sizeof(u32)) ||
+            if (ctx->tail_done.reserve(2 * (size_t)tp.tail_groups * sizeof(u32)) ||       // finished pieces, claimed pieces
                 ctx->tail_park.reserve((size_t)tp.tail_groups * PARK_WORDS * 64 * sizeof(u64)))
                 return SSA_ERR_HIP;
-            HIP_TRY(hipMemsetAsync(ctx->tail_done.p, 0, (size_t)tp.tail_groups * sizeof(u32), ctx->stream));
+            HIP_TRY(hipMemsetAsync(ctx->tail_done.p, 0, 2 * (size_t)tp.tail_groups * sizeof(u32), ctx->stream));
             blocks = tail_grid_blocks(tp);
         }
         int rc = timed_launch(ctx, "ssa_k_verify", [&] {

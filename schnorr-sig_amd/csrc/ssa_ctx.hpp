@@ -112,6 +112,7 @@ struct ssa_ctx {
     unsigned tail_pieces = 5;     // SSA_TAIL_PIECES (0 or 1: off); launches of less than one generation have none
     unsigned tail_gens = 1;       // SSA_TAIL_GENS: tail groups, in generations of resident waves
     bool tail_uniform = false;    // SSA_TAIL_UNIFORM=1: equal pieces instead of 1/2, 1/4, 1/8, ...
+    bool tail_reversed = false;   // SSA_TAIL_REVERSED=1 (tests): the end game's roles dealt from the end of the grid
     unsigned tail_min_main = 0;   // SSA_TAIL_MIN_MAIN: generations of ordinary workgroups a launch must have beside its tail
     unsigned tail_waves_override = 0;   // SSA_TAIL_WAVES: the tests' small "generation" (the end game on batches of thousands)
     DevBuf tail_done, tail_park;  // per tail group: finished pieces; parked accumulators + status (152 B per lane)

@@ -544,11 +544,11 @@ __device__ unsigned long long g_wave_times[3 * SSA_WAVE_TIMES_MAX];
 // accumulator and status are parked in HBM, lane-interleaved; the lanes' tables stay where they are.  Everything else is
 // the launch it always was: no counter, no persistent wave.
 //   grid: [piece 0][ordinary workgroups][piece 1][piece 2] ... [piece P-1]; a piece workgroup runs four tail groups.
-// Workgroups are dispatched in grid order, so piece p - 1 of a group was dispatched before its piece p (a whole launch
-// before, for piece 0); correctness does not rest on that: done[g] counts the finished pieces (release after the parked
-// state and, for piece 0, the tables are written; acquire before they are read: the XCDs' L2s are not coherent with each
-// other), and a wave whose predecessor has not finished sleeps on the flag -- the predecessor's workgroup precedes it in
-// the grid and is resident or done.
+// done[g] counts the finished pieces of tail group g (release after the parked state and, for piece 0, the tables are
+// written; acquire before they are read: the XCDs' L2s are not coherent with each other), and a wave whose predecessor has
+// not finished sleeps on the flag.  Workgroups are dispatched in grid order, so the predecessor started long before;
+// liveness does not rest on that: pieces are CLAIMED (done[K + g] = first unclaimed piece of group g), a wave takes any
+// earlier piece nobody has claimed along with its own, and therefore only ever waits for a piece a running wave holds.
 constexpr int VP_MAX = 8;
 struct TailPlan {
     u32 n_pieces;            // 0: no end game (every workgroup is an ordinary one)
@@ -556,6 +556,7 @@ struct TailPlan {
     u32 main_blocks;         // ordinary workgroups (256 lanes each): lanes [0, 256 * main_blocks)
     u32 ph[VP_MAX];          // piece p: pass | first-of-pass << 1 | last-of-pass << 2 | it_lo << 8 | it_hi << 16
     u32 whole[2];            // the same descriptor for a whole pass 0 / pass 1 (ordinary workgroups)
+    u32 reversed;            // test hook (SSA_TAIL_REVERSED=1): roles dealt from the END of the grid, the worst dispatch order
 };
 __host__ __device__ inline u32 tail_grid_blocks(const TailPlan &tp) { return tp.main_blocks + tp.n_pieces * (tp.tail_groups / 4u); }
 struct BlockRole {
@@ -619,7 +620,7 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
     // piece of four tail groups (wave w: tail group 4 * index + w).  (Measured and dropped: the closing waves pulling
     // their (piece, group) jobs from a counter until it runs dry, so that the faster XCDs take more -- the XCDs then do
     // finish together, 0.4 ms LATER: profiles/r05/end_game_ab.txt.)
-    const BlockRole role = tail_role(tp, blockIdx.x);
+    const BlockRole role = tail_role(tp, tp.reversed ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
     const u32 lane = threadIdx.x & 63u;
     const bool in_piece = role.piece != 0xffffffffu;
     const u32 p_lo = in_piece ? role.piece : 0u;
@@ -633,12 +634,34 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
     u32 status = ST_OK;
     bool ok_sig = true;
     jac r = jac_identity();
-    if (in_piece && p_lo > 0) {
-        while (__hip_atomic_load(done + eg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < p_lo) __builtin_amdgcn_s_sleep(64);
+    // Which pieces this wave runs: its own -- and any earlier piece of the group that nobody has CLAIMED yet.  Every piece
+    // wave claims at its start (next[g] = first unclaimed piece of tail group g, one compare-and-swap per wave).  In grid
+    // order the predecessor has claimed piece p_lo - 1 long ago and this wave claims exactly p_lo; if a dispatcher ever
+    // started this workgroup BEFORE its predecessor's, the wave takes the unclaimed pieces too and the late-comer, finding
+    // its piece claimed, leaves at once.  So a wave only ever waits for pieces that a RUNNING wave has claimed: every wave of
+    // the grid reaches its end whatever the dispatch order, and no piece is run twice.
+    u32 run_lo = p_lo;
+    if (in_piece) {
+        u32 *next = done + tp.tail_groups + eg;
+        u32 cur = 0;
+        if (lane == 0) {
+            cur = __hip_atomic_load(next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (cur <= p_lo) {
+                const u32 seen = atomicCAS(next, cur, p_lo + 1u);
+                if (seen == cur) break;
+                cur = seen;
+            }
+        }
+        cur = (u32)__builtin_amdgcn_readfirstlane((int)cur);
+        if (cur > p_lo) return;                       // another wave runs this piece
+        run_lo = cur;
+    }
+    if (in_piece && run_lo > 0) {
+        while (__hip_atomic_load(done + eg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < run_lo) __builtin_amdgcn_s_sleep(64);
         const u64 sw = pk[18 * 64];
         status = (u32)(sw & 0xffu);
         ok_sig = ((sw >> 8) & 1u) != 0;
-        if (in && status == ST_OK && !(tp.ph[p_lo] & 2u)) r = park_load(pk);              // (a pass's first piece starts afresh)
+        if (in && status == ST_OK && !(tp.ph[run_lo] & 2u)) r = park_load(pk);            // (a pass's first piece starts afresh)
     } else if (in) {
         // check order of the reference (src/signature.rs:181-205): the key first (subgroup check, :182),
         // then the signature's x (Fp6::from_bytes(..).unwrap() panics at :186 -> SSA_MALFORMED)
@@ -664,7 +687,7 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
         for (int k = 0; k < 4; k++) h.w[k] = h_in[4 * i + k];
         const sc256 kr = sc_recode_offset5(h);
         // the descriptors this wave runs: one piece, or the whole passes (pass 0 only with the subgroup check)
-        const u32 d_lo = in_piece ? p_lo : ((flags & VF_CHECK_TORSION) ? 0u : 1u);
+        const u32 d_lo = in_piece ? run_lo : ((flags & VF_CHECK_TORSION) ? 0u : 1u);
         const u32 d_hi = in_piece ? p_lo + 1u : 2u;
 #pragma unroll 1
         for (u32 k = d_lo; k < d_hi; k++) {
@@ -722,7 +745,7 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
         // agent-scope stores already, and the flag just has to follow them
         if (in && status == ST_OK) park_store(pk, r);
         st_shared(pk + 18 * 64, (u64)status | ((u64)(ok_sig ? 1u : 0u) << 8));
-        if (p_lo == 0) {
+        if (run_lo == 0) {
             __hip_atomic_store(done + eg, p_lo + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -278,12 +278,12 @@ def test_pubkey_many_is_one_base_multiplication(engine, oracle):
 
 
 # ---------------------------------------------------------------- the end game of ssa_k_verify
-def _tail_engine(pieces, waves=32, gens=1, uniform=False):
+def _tail_engine(pieces, waves=32, gens=1, uniform=False, reversed_grid=False):
     """an engine whose "generation" is `waves` waves, so that batches of thousands run the end game: the last generation of
     lanes in `pieces` pieces with the accumulator parked in between (read at ssa_ctx_create)"""
     import schnorr_sig_amd as ssa
     env = {"SSA_TAIL_WAVES": str(waves), "SSA_TAIL_PIECES": str(pieces), "SSA_TAIL_GENS": str(gens),
-           "SSA_TAIL_UNIFORM": "1" if uniform else "0"}
+           "SSA_TAIL_UNIFORM": "1" if uniform else "0", "SSA_TAIL_REVERSED": "1" if reversed_grid else "0"}
     os.environ.update(env)
     try:
         return ssa.Engine(0)
@@ -292,12 +292,16 @@ def _tail_engine(pieces, waves=32, gens=1, uniform=False):
             del os.environ[k]
 
 
-@pytest.mark.parametrize("pieces,gens,uniform", [(2, 1, False), (3, 1, False), (5, 2, False), (8, 1, False), (4, 1, True), (7, 3, True)])
-def test_end_game_pieces_equal_whole_lanes(engine, oracle, pieces, gens, uniform):
+@pytest.mark.parametrize("pieces,gens,uniform,reversed_grid",
+                         [(2, 1, False, False), (3, 1, False, False), (5, 2, False, False), (8, 1, False, False),
+                          (4, 1, True, False), (7, 3, True, False), (5, 1, False, True), (8, 2, True, True)])
+def test_end_game_pieces_equal_whole_lanes(engine, oracle, pieces, gens, uniform, reversed_grid):
     """ssa_k_verify with its last generation(s) of lanes cut into pieces (accumulator and status parked between them, flags
     with release / acquire) gives the status vector of the plain launch and of the oracle: every corruption class, malformed
     inputs, identity keys and the non-subgroup fixture INSIDE the tail groups, subgroup check (two passes: a piece never
-    spans them) and flag byte on and off, a ragged last group"""
+    spans them) and flag byte on and off, a ragged last group.  reversed_grid deals the roles from the END of the grid -- the
+    closing pieces' workgroups start first, the worst order a dispatcher could choose: a wave then takes the unclaimed
+    earlier pieces of its group along with its own and the late-comers leave (no wave waits for one that has not started)"""
     rng = np.random.default_rng(5400 + pieces)
     waves = 32
     n = (2 + gens) * waves * 64 + 1000 + 37                 # tail = the last gens * 2048 lanes (+ the ragged remainder)
@@ -316,7 +320,7 @@ def test_end_game_pieces_equal_whole_lanes(engine, oracle, pieces, gens, uniform
     sigs[t[8], 48] ^= 0x40                                    # the other root of R (flag-byte semantics only)
     sigs[t[9], 48] |= 2                                       # undecodable flag byte
     sigs[t[10], 49:] = np.frombuffer(Q.to_bytes(32, "little"), np.uint8)   # e = q
-    eng = _tail_engine(pieces, waves, gens, uniform)
+    eng = _tail_engine(pieces, waves, gens, uniform, reversed_grid)
     try:
         for torsion in (False, True):
             for fb in (False, True):
