@@ -401,6 +401,13 @@ int ssa_debug_arith(ssa_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, 
  * has been enqueued (one shot; chunk < 0 disarms).  Replaces round 3's SSA_FAULT_AFTER_CHUNK environment variable: the
  * production path reads no environment per call. */
 int ssa_debug_fault_after_chunk(ssa_ctx *ctx, int chunk);
+/* host logic of ssa_k_verify's end game, no context and no device needed: the launch plan for n lanes when `waves`
+ * waves are resident (pieces / gens / uniform / min_main: what SSA_TAIL_PIECES, _GENS, _UNIFORM, _MIN_MAIN set).
+ * out: number of pieces (0: no end game), 64-lane tail groups, ordinary workgroups, workgroups of the grid, the eight
+ * piece descriptors (pass | first-of-pass << 1 | last-of-pass << 2 | first window << 8 | end window << 16) and the two
+ * whole-pass descriptors ([q]P of the subgroup check, [h]P). */
+int ssa_debug_tail_plan(unsigned waves, unsigned pieces, unsigned gens, int uniform, unsigned min_main, size_t n,
+                        uint32_t flags, uint32_t out[14]);
 /* n_blocks 64-byte blocks of the ChaCha20 keystream the MSM coefficients come from (RFC 8439 known answers) */
 int ssa_debug_chacha20(ssa_ctx *ctx, const uint8_t key[32], const uint8_t nonce[12], uint32_t counter0,
                        size_t n_blocks, uint8_t *out);

@@ -172,6 +172,7 @@ def _load():
         "ssa_ctx_stream_release": (i32, [vp, vp]),
         "ssa_ctx_stream_acquire": (i32, [vp, vp]),
         "ssa_debug_fault_after_chunk": (i32, [vp, i32]),
+        "ssa_debug_tail_plan": (i32, [u32, u32, u32, i32, u32, sz, u32, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here == ABI symbol missing: fail loudly
@@ -661,6 +662,21 @@ class MultiEngine:
 
 
 _default_engine = None
+
+
+def debug_tail_plan(waves, n, check_torsion=False, pieces=5, gens=1, uniform=False, min_main=0):
+    """host logic of ssa_k_verify's end game (no device needed): the launch plan for n lanes with `waves` resident waves.
+    Returns a dict: n_pieces, tail_groups, main_blocks, grid_blocks, pieces = [(pass, first, last, lo, hi)], whole"""
+    out = np.zeros(14, dtype=np.uint32)
+    flags = 1 if check_torsion else 0            # SSA_FLAG_CHECK_TORSION
+    _check(_lib.ssa_debug_tail_plan(int(waves), int(pieces), int(gens), int(bool(uniform)), int(min_main), int(n), flags,
+                                    out.ctypes.data), "ssa_debug_tail_plan")
+
+    def dec(d):
+        d = int(d)
+        return (d & 1, bool(d & 2), bool(d & 4), (d >> 8) & 0xff, (d >> 16) & 0xff)
+    return {"n_pieces": int(out[0]), "tail_groups": int(out[1]), "main_blocks": int(out[2]), "grid_blocks": int(out[3]),
+            "pieces": [dec(out[4 + k]) for k in range(int(out[0]))], "whole": [dec(out[12]), dec(out[13])]}
 
 
 def default_engine():

@@ -550,16 +550,26 @@ static inline MsgView msg_slice(const MsgView &mv, size_t lo) {
 // the first pass, the comb for G and the comparison ~45 k behind the last): the first piece is half of a lane's work, the
 // next a quarter, ... the last two equal (SSA_TAIL_UNIFORM=1: equal pieces); a piece never spans the two passes of
 // SSA_FLAG_CHECK_TORSION.
+struct TailKnobs {
+    unsigned pieces, gens, waves, block, min_main;
+    bool uniform, reversed;
+};
+static TailPlan tail_plan_of(const TailKnobs &kn, size_t cnt, uint32_t flags);
 static TailPlan tail_plan(const ssa_ctx *ctx, size_t cnt, uint32_t flags) {
+    return tail_plan_of({ctx->tail_pieces, ctx->tail_gens, ctx->verify_waves, ctx->verify_block, ctx->tail_min_main,
+                         ctx->tail_uniform, ctx->tail_reversed}, cnt, flags);
+}
+static TailPlan tail_plan_of(const TailKnobs &kn, size_t cnt, uint32_t flags) {
+    const TailKnobs *ctx = &kn;
     TailPlan tp{};
     const bool torsion = (flags & SSA_FLAG_CHECK_TORSION) != 0;
     tp.whole[0] = 0u | 2u | 4u | ((u32)LADDER_STEPS_Q << 16);
     tp.whole[1] = 1u | 2u | 4u | ((u32)LADDER_STEPS << 16);
     const u32 n_groups = (u32)((cnt + 63) / 64);
     const unsigned cap = torsion ? (unsigned)VP_MAX - 1u : (unsigned)VP_MAX;      // (the pass boundary is one more cut)
-    const unsigned want = ctx->tail_pieces < cap ? ctx->tail_pieces : cap;
-    const u32 tail0 = ctx->tail_gens * ctx->verify_waves;
-    if (want < 2 || ctx->verify_block != 256 || tail0 == 0 || n_groups < tail0 + ctx->tail_min_main * ctx->verify_waves) return tp;
+    const unsigned want = ctx->pieces < cap ? ctx->pieces : cap;
+    const u32 tail0 = ctx->gens * ctx->waves;
+    if (want < 2 || ctx->block != 256 || tail0 == 0 || n_groups < tail0 + ctx->min_main * ctx->waves) return tp;
     const u32 main_groups = ((n_groups - tail0) / 4u) * 4u;
     tp.main_blocks = main_groups / 4u;
     tp.tail_groups = ((n_groups - main_groups + 3u) / 4u) * 4u;
@@ -577,7 +587,7 @@ static TailPlan tail_plan(const ssa_ctx *ctx, size_t cnt, uint32_t flags) {
     std::vector<double> target;
     double frac = 0.0, f = 0.5;
     for (unsigned k = 0; k + 1 < want; k++) {
-        frac += ctx->tail_uniform ? 1.0 / (double)want : f;
+        frac += ctx->uniform ? 1.0 / (double)want : f;
         if (k + 2 < want) f *= 0.5;
         target.push_back(total * frac);
     }
@@ -605,8 +615,25 @@ static TailPlan tail_plan(const ssa_ctx *ctx, size_t cnt, uint32_t flags) {
         const int n_steps = pass == 0 ? LADDER_STEPS_Q : LADDER_STEPS;
         tp.ph[tp.n_pieces++] = (u32)pass | (lo == 0 ? 2u : 0u) | (hi == n_steps ? 4u : 0u) | ((u32)lo << 8) | ((u32)hi << 16);
     }
-    tp.reversed = ctx->tail_reversed ? 1u : 0u;
+    tp.reversed = ctx->reversed ? 1u : 0u;
     return tp;
+}
+
+// the plan for explicit knobs: no context and no device needed, so the host logic is tested on the CPU
+// (tests/test_tail_plan.py: the pieces cover every window of every pass exactly once and never span two passes, the
+// grid is what the kernel assumes).  out: n_pieces, tail_groups, main_blocks, grid blocks, ph[0..7], whole[0..1].
+extern "C" int ssa_debug_tail_plan(unsigned waves, unsigned pieces, unsigned gens, int uniform, unsigned min_main, size_t n,
+                                   uint32_t flags, uint32_t out[14]) {
+    if (!out) return SSA_ERR_ARG;
+    const TailPlan tp = tail_plan_of({pieces, gens, waves, 256u, min_main, uniform != 0, false}, n, flags);
+    out[0] = tp.n_pieces;
+    out[1] = tp.tail_groups;
+    out[2] = tp.main_blocks;
+    out[3] = tp.n_pieces ? tail_grid_blocks(tp) : (uint32_t)((n + 255) / 256);
+    for (int k = 0; k < VP_MAX; k++) out[4 + k] = tp.ph[k];
+    out[12] = tp.whole[0];
+    out[13] = tp.whole[1];
+    return 0;
 }
 
 // ssa_k_verify over n lanes whose challenge scalars are in d_h, in slices of at most ctx->lane_slice lanes: the 4 KB

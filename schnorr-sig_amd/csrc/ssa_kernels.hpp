@@ -657,7 +657,9 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
         run_lo = cur;
     }
     if (in_piece && run_lo > 0) {
-        while (__hip_atomic_load(done + eg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < run_lo) __builtin_amdgcn_s_sleep(64);
+        // (the wait itself relaxed, ONE acquire behind it: an acquiring load invalidates the XCD's L2 every time it is issued)
+        while (__hip_atomic_load(done + eg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < run_lo) __builtin_amdgcn_s_sleep(64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const u64 sw = pk[18 * 64];
         status = (u32)(sw & 0xffu);
         ok_sig = ((sw >> 8) & 1u) != 0;
