@@ -464,7 +464,11 @@ SSA_DEV jac ladder_steps(jac acc, const u64 *__restrict__ tab, const sc256 &kr, 
 #ifdef SSA_JAC_ASM
         // one asm statement per window: `gap` doublings + the addition on the lanes with a non-zero digit; -y comes from
         // the table, so the loop body outside the statement is the digit, one address and six loads
+#ifdef SSA_GATHER_HOT    // timing only (wrong results): every window adds entry 0 -- what the gather's HBM latency costs
+        const u64 *row = tab;
+#else
         const u64 *row = tab + (size_t)((mag ? mag : 1) - 1) * PTAB_ENTRY_U64 + (digit < 0 ? PTAB_NEG : 0);
+#endif
         aff q;
         q.x = ld_f6(row);
         q.y = ld_f6(row + 6);
