@@ -41,10 +41,12 @@ __host__ __device__ inline size_t gtab_entries(u32 bits) { return (size_t)gtab_w
 __host__ __device__ inline size_t gbase_entries(u32 bits) { return ((size_t)gtab_windows(bits) * 2) << (bits / 2); }
 __host__ __device__ inline u64 gtab_header(u32 bits) { return (u64)bits | ((u64)gtab_windows(bits) << 8); }
 SSA_DEV GtabGeom gtab_geom(const u64 *__restrict__ gtab) {
-    const u64 v = gtab[0];
+    // (the same word for every lane: read once into scalar registers, so that the geometry costs no vector register and
+    // the window arithmetic of the comb loops runs on the scalar unit)
+    const u32 v = (u32)__builtin_amdgcn_readfirstlane((int)(u32)gtab[0]);
     GtabGeom g;
-    g.bits = (u32)(v & 0xffu);
-    g.count = (u32)((v >> 8) & 0xffu);
+    g.bits = v & 0xffu;
+    g.count = (v >> 8) & 0xffu;
     return g;
 }
 constexpr int PTAB_ENTRIES = 16;    // 1P..16P: signed 5-bit windows (round 4; 1P..8P and 4-bit windows before)
@@ -448,7 +450,9 @@ SSA_DEV jac ladder_init(const u64 *__restrict__ tab, const sc256 &kr, bool order
     }
     return acc;
 }
-SSA_DEV jac ladder_steps(jac acc, const u64 *__restrict__ tab, const sc256 &kr, bool order_q, int lo, int hi) {
+// (tab by reference: the window statement hands the pointer through and so keeps it in a register, jac_asm.inc; the
+// caller goes on with the statement's copy, so that no second copy of it stays live -- in scratch -- across the loop)
+SSA_DEV jac ladder_steps(jac acc, const u64 *&tab, const sc256 &kr, bool order_q, int lo, int hi) {
 #pragma unroll 1
     for (int it = lo; it < hi; it++) {
         int digit;
@@ -463,17 +467,20 @@ SSA_DEV jac ladder_steps(jac acc, const u64 *__restrict__ tab, const sc256 &kr, 
         const int mag = digit < 0 ? -digit : digit;
 #ifdef SSA_JAC_ASM
         // one asm statement per window: `gap` doublings + the addition on the lanes with a non-zero digit; -y comes from
-        // the table, so the loop body outside the statement is the digit, one address and six loads
+        // the table and the statement gathers its entry itself (six loads issued in front of the doublings, awaited behind
+        // them): the loop body outside the statement is the digit and one address
 #ifdef SSA_GATHER_HOT    // timing only (wrong results): every window adds entry 0 -- what the gather's HBM latency costs
         const u64 *row = tab;
 #else
         const u64 *row = tab + (size_t)((mag ? mag : 1) - 1) * PTAB_ENTRY_U64 + (digit < 0 ? PTAB_NEG : 0);
 #endif
-        aff q;
-        q.x = ld_f6(row);
-        q.y = ld_f6(row + 6);
-        if (!jac_window_asm(acc.X.c, acc.Y.c, acc.Z.c, q.x.c, q.y.c, (u32)mag, gap)) {
-            if (digit != 0) acc = jac_madd(acc, q);      // exceptional inputs: the exact compiled addition
+        if (__builtin_expect(!jac_window_asm(acc.X.c, acc.Y.c, acc.Z.c, row, (u32)mag, gap, tab), 0)) {
+            if (digit != 0) {                            // exceptional inputs: the exact compiled addition
+                aff q;
+                q.x = ld_f6(row);
+                q.y = ld_f6(row + 6);
+                acc = jac_madd(acc, q);
+            }
         }
 #else
         acc = jac_dbl_n(acc, gap);
@@ -486,23 +493,53 @@ SSA_DEV jac ladder_steps(jac acc, const u64 *__restrict__ tab, const sc256 &kr, 
     }
     return acc;
 }
-SSA_DEV jac mul_ptab(const u64 *__restrict__ tab, const sc256 &k, bool order_q = false) {
+SSA_DEV jac mul_ptab(const u64 *__restrict__ tab_in, const sc256 &k, bool order_q = false) {
     const sc256 kr = sc_recode_offset5(k);
+    const u64 *tab = tab_in;
     return ladder_steps(ladder_init(tab, kr, order_q), tab, kr, order_q, 0, order_q ? LADDER_STEPS_Q : LADDER_STEPS);
 }
 
-// acc += [e]G from the comb table: one mixed addition per non-zero window of e (the table's own geometry)
-SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e) {
-    const GtabGeom gg = gtab_geom(gtab);
+// The mixed addition on a comb table's entry: the statement gathers the entry itself and touches the one the NEXT
+// addition will want (jac_asm.inc: jac_madd_gather_asm) -- comb entries lie at random places of tables far larger than
+// the caches, and an addition that waits for its operand in front of the statement waits for the whole HBM latency.
+// (base by reference: the statement hands the table's base through in a register, as the ladder's window does)
+SSA_DEV jac jac_madd_gather(const jac &p, const u64 *row, const u64 *next, const u64 *&base) {
+#ifdef SSA_JAC_ASM
+    jac r = p;
+    if (__builtin_expect(jac_madd_gather_asm(r.X.c, r.Y.c, r.Z.c, row, next, base) != 0, 1)) return r;
+    return jac_madd(r, ld_aff(row));      // r is untouched: identity, (0, 0) entries, P == +-Q
+#else
+    (void)next;
+    (void)base;
+    return jac_madd(p, ld_aff(row));
+#endif
+}
+
+// acc += sum over the windows of k of table[w][window w of k]: one mixed addition per non-zero window (`count` windows of
+// `bits` bits, entry d of window w at base + ((w << bits) + d) * 12)
+SSA_DEV jac comb_add(jac acc, const u64 *__restrict__ base_in, const sc256 &k, u32 bits, u32 count, bool hot = false) {
+    const u64 *base = base_in;
 #pragma unroll 1
-    for (u32 w = 0; w < gg.count; w++) {
-        const u32 d = sc_bits(e, w * gg.bits, gg.bits);
+    for (u32 w = 0; w < count; w++) {
+        const u32 d = sc_bits(k, w * bits, bits);
         if (d != 0) {
-            const aff q = ld_aff(gtab + (((size_t)w << gg.bits) + d) * 12);
-            acc = jac_madd_fast(acc, q);
+            const u32 w1 = w + 1 < count ? w + 1 : w;      // (the last addition touches its own entry again)
+            const u64 *next = base + (((size_t)w1 << bits) + sc_bits(k, w1 * bits, bits)) * 12;
+#ifdef SSA_COMB_HOT       // timing only (wrong results): every window adds the same entry -- what the comb gathers' latency costs
+            const u64 *row = base + (hot ? (size_t)12 : (((size_t)w << bits) + d) * 12);
+#else
+            const u64 *row = base + (((size_t)w << bits) + d) * 12;
+#endif
+            acc = jac_madd_gather(acc, row, next, base);
         }
     }
     return acc;
+}
+
+// acc += [e]G from the comb table of the generator (the table's own geometry)
+SSA_DEV jac add_base_mul(jac acc, const u64 *__restrict__ gtab, const sc256 &e, bool hot = false) {
+    const GtabGeom gg = gtab_geom(gtab);
+    return comb_add(acc, gtab, e, gg.bits, gg.count, hot);
 }
 
 // CompressedPoint flag byte of a signature's x under verify_batch semantics (SSA_FLAG_SIG_FLAG_BYTE): the
@@ -695,6 +732,7 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
         // the descriptors this wave runs: one piece, or the whole passes (pass 0 only with the subgroup check)
         const u32 d_lo = in_piece ? run_lo : ((flags & VF_CHECK_TORSION) ? 0u : 1u);
         const u32 d_hi = in_piece ? p_lo + 1u : 2u;
+        const u64 *ltab = tab;                              // (the ladder's copy: ladder_steps)
 #pragma unroll 1
         for (u32 k = d_lo; k < d_hi; k++) {
             const u32 d = in_piece ? tp.ph[k] : tp.whole[k];
@@ -704,9 +742,9 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
                     status = ST_MALFORMED;
                     break;
                 }
-                r = ladder_init(tab, kr, pass_q);
+                r = ladder_init(ltab, kr, pass_q);
             }
-            r = ladder_steps(r, tab, kr, pass_q, (int)((d >> 8) & 0xffu), (int)((d >> 16) & 0xffu));
+            r = ladder_steps(r, ltab, kr, pass_q, (int)((d >> 8) & 0xffu), (int)((d >> 16) & 0xffu));
             if (last && pass_q && !jac_is_identity(r)) {
                 status = ST_INVALID_PK;
                 break;
@@ -720,7 +758,11 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
                 const fp6 xs = ld_fp6(sigs + 81 * i, okx);
                 const sc256 e = ld_sc(sigs + 81 * i + 49);
                 const u32 fbyte = sigs[81 * i + 48];
+#ifdef SSA_COMB_HOT
+                r = add_base_mul(r, gtab, e, true);
+#else
                 r = add_base_mul(r, gtab, e);               // + [e]G, :196-198
+#endif
                 // r.get_x() == x_felt (:200): X == x * Z^2; the identity's x is taken as 0
                 bool eq;
                 if (flags & VF_SIG_FLAG_BYTE) {
@@ -731,7 +773,9 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
                         eq = !jac_is_identity(r) && f6_eq(r.X, f6_mul(xs, f6_sqr(r.Z)));
                         if (eq) eq = jac_y_lex_largest(r) == ((fbyte & 0x40u) != 0);
                         // an x with no curve point: from_compressed is None, the reference panics
+#ifndef SSA_COMB_HOT
                         else if (!x_on_curve(xs)) ok_sig = false;
+#endif
                     }
                 } else if (jac_is_identity(r)) {
                     eq = f6_is_zero(xs);
@@ -977,13 +1021,9 @@ ssa_k_verify_keyed_comb(const u8 *__restrict__ sigs, const u32 *__restrict__ key
             sc256 h;
 #pragma unroll
             for (int j = 0; j < 4; j++) h.w[j] = h_in[4 * i + j];
-            jac r = jac_identity();
-#pragma unroll 1
-            for (int w = 0; w < KW_COUNT; w++) {          // [h]P: one mixed addition per non-zero 16-bit window of h
-                const u32 d = sc_bits(h, (u32)w * (u32)KW_BITS, (u32)KW_BITS);
-                if (d != 0) r = jac_madd_fast(r, ld_aff(tab + (((size_t)w << KW_BITS) + d) * 12));
-            }
-            r = add_base_mul(r, gtab, e);
+            // [h]P: one mixed addition per non-zero 16-bit window of h, from the key's comb
+            jac r = comb_add(jac_identity(), tab, h, (u32)KW_BITS, (u32)KW_COUNT);
+            r = add_base_mul(r, gtab, ld_sc(sigs + 81 * i + 49));     // (e read again: not held -- in scratch -- across [h]P)
             bool eq;
             if (flags & VF_SIG_FLAG_BYTE) {
                 if (fbyte & 0x80u) {
@@ -1456,7 +1496,8 @@ ssa_k_debug_mul(int op, const u64 *__restrict__ a, const u64 *__restrict__ b, si
         }
         u32 flag = 1;
 #ifdef SSA_JAC_ASM
-        if (op == 15) flag = jac_window_asm(p.X.c, p.Y.c, p.Z.c, q.x.c, q.y.c, (u32)pa[18], (u32)pa[19]);
+        const u64 *keep = pb;
+        if (op == 15) flag = jac_window_asm(p.X.c, p.Y.c, p.Z.c, pb, (u32)pa[18], (u32)pa[19], keep);    // (gathers x2, y2 itself)
         else
 #endif
         if (op == 16) p = jac_madd_fast(p, q);

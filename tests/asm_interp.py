@@ -158,6 +158,22 @@ class Lane:
                 self.salu32[k], self.salu32[k + 1] = t & M32, (t >> 32) & M32
             elif op == "s_waitcnt":
                 pass
+            # ---- the window statement gathers its own table entry: `self.mem[operand]` is the list of 32-bit words at the
+            # address the operand holds (a test sets it); one lane, no latency: the load lands at once
+            elif op == "global_load_dword":     # (the touches of jac_madd_gather_asm: a word loaded to be dropped)
+                mo = re.match(r"off(?:\s+offset:(\d+))?$", a[2])
+                words = self.mem[a[1]]
+                self.v[int(re.match(r"v(\d+)$", a[0]).group(1))] = words[int(mo.group(1) or 0) // 4] & M32
+            elif op == "global_load_dwordx4":
+                m = re.match(r"v\[(\d+):(\d+)\]$", a[0])
+                lo, hi = int(m.group(1)), int(m.group(2))
+                assert hi == lo + 3 and lo % 2 == 0
+                mo = re.match(r"off(?:\s+offset:(\d+))?$", a[2])
+                off = int(mo.group(1) or 0)
+                assert off % 4 == 0
+                words = self.mem[a[1]]
+                for k in range(4):
+                    self.v[lo + k] = words[off // 4 + k] & M32
             elif op == "s_lshr_b32":
                 self.salu32[int(a[0][1:])] = (self.salu32.get(int(a[1][1:]), 0) >> int(a[2], 0)) & M32
             elif op == "s_getreg_b32":

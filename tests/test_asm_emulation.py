@@ -520,12 +520,82 @@ def test_generated_mixed_addition_and_window_on_the_cpu():
             pt[0][0] = u[0] if case == 4 or u[0] + P >= 2**64 else u[0] + P
         got, ok = run(lines, x2r, y2r, pt, q, {})
         assert ok == 0 and got == [[c % P for c in v] for v in pt], case
+    # the window statement gathers (x2, y2) itself: six 16-byte loads from the lane's table row at its start, one wait
+    # behind the doublings and in front of the EXEC narrowing (every path out of the statement passes it)
     lines, x2r, y2r = _asm_fn(txt, "jac_window_asm")
+    assert x2r == [] and y2r == []
+    loads = [ln for ln in lines if ln.startswith("global_load")]
+    assert lines[0] == "s_waitcnt vmcnt(0)"       # nothing of the compiler's in flight when the statement starts (gen_jac_asm.py)
+    assert len(loads) == 6 and lines[1:7] == loads
+    wait = lines.index("s_waitcnt vmcnt(0)", 1)
+    assert lines[wait + 1].startswith("v_cmp_ne_u32 vcc, 0, %[act]") and lines[wait - 1].startswith("s_cbranch_scc1 L_top")
+    assert not any(ln.startswith("s_waitcnt") for i, ln in enumerate(lines) if i not in (0, wait))
+    in_regs = gj.build_madd("m").IN
+    x2r, y2r = in_regs[:6], in_regs[6:]
+
+    def run_window(pt, q, env):
+        lane = ai.Lane(dict(env, **{"%[ok]": 7}))
+        lane.mem = {"%[row]": [w for coord in q for c in coord for w in (c & M32, c >> 32)]}
+        for regs, val in zip((gj.XR, gj.YR, gj.ZR), pt):
+            for j in range(6):
+                lane.v[regs[j]], lane.v[regs[j] + 1] = val[j] & M32, val[j] >> 32
+        for r in x2r + y2r:                       # whatever the registers held before the statement must not matter
+            lane.v[r], lane.v[r + 1] = 0xDEADBEEF, 0xFEEDFACE
+        lane.run(lines)
+        assert getattr(lane, "exec_bit", 1) == 1
+        return [[(lane.v[r] | (lane.v[r + 1] << 32)) % P for r in regs] for regs in (gj.XR, gj.YR, gj.ZR)], lane.env["%[ok]"]
+
+    # the mixed addition that gathers its own operand (comb tables): the same cases as jac_madd_asm through the loads; the
+    # additions' loads are awaited once, in front of the first use of (x2, y2), the touches of the next entry at the end
+    glines, gx, gy = _asm_fn(txt, "jac_madd_gather_asm")
+    assert gx == [] and gy == []
+    assert glines[0] == "s_waitcnt vmcnt(0)"
+    assert [ln.split()[0] for ln in glines[1:9]] == ["global_load_dwordx4"] * 6 + ["global_load_dword"] * 2
+    qwait = glines.index("s_waitcnt vmcnt(2)")
+    first_use = min(i for i, ln in enumerate(glines) if i >= 9 and re.search(r"\bv(%s)\b" % "|".join(str(r + h) for r in in_regs for h in (0, 1)), ln))
+    assert qwait < first_use and glines[-1] == "s_waitcnt vmcnt(0)" and glines[-2].startswith("L_end")
+    assert sum(ln.startswith("s_waitcnt") for ln in glines) == 3
+
+    def run_gather(pt, q):
+        lane = ai.Lane({"%[ok]": 7})
+        words = [w for coord in q for c in coord for w in (c & M32, c >> 32)]
+        lane.mem = {"%[row]": words, "%[next]": [0x5A5A5A5A] * 24}
+        for regs, val in zip((gj.XR, gj.YR, gj.ZR), pt):
+            for j in range(6):
+                lane.v[regs[j]], lane.v[regs[j] + 1] = val[j] & M32, val[j] >> 32
+        for r in x2r + y2r:
+            lane.v[r], lane.v[r + 1] = 0xDEADBEEF, 0xFEEDFACE
+        lane.run(glines)
+        return [[(lane.v[r] | (lane.v[r + 1] << 32)) % P for r in regs] for regs in (gj.XR, gj.YR, gj.ZR)], lane.env["%[ok]"]
+
+    generic = 0
+    for kind in ["rand"] * 4 + ["edge"] * 6 + ["max", "hi", "hi", "hi"]:
+        pt, q = [elem(kind) for _ in range(3)], [elem(kind) for _ in range(2)]
+        got, ok = run_gather(pt, q)
+        want, H = _jac_madd_model(*pt, *q)
+        if pt[2][0] % P == 0 or q[0][0] % P == 0 or H[0] == 0:
+            assert ok == 0 and got == [[c % P for c in v] for v in pt]
+        else:
+            generic += 1
+            assert ok == 1 and got == want, kind
+    assert generic >= 10
+    for case in range(6):        # exceptional inputs
+        pt, q = [elem("rand") for _ in range(3)], [elem("rand") for _ in range(2)]
+        if case < 2:
+            pt[2][0] = (0, P)[case]
+        elif case < 4:
+            q[0][0] = (0, P)[case - 2]
+        else:
+            u = _f6_mulmod(q[0], _f6_mulmod(pt[2], pt[2]))
+            pt[0][0] = u[0] if case == 4 or u[0] + P >= 2**64 else u[0] + P
+        got, ok = run_gather(pt, q)
+        assert ok == 0 and got == [[c % P for c in v] for v in pt], case
+
     for kind in ["rand", "rand", "hi", "max"]:
         for act in (0, 5):
             for n in (1, 4):
                 pt, q = [elem(kind) for _ in range(3)], [elem(kind) for _ in range(2)]
-                got, ok = run(lines, x2r, y2r, pt, q, {"%[act]": act, "%[n]": n})
+                got, ok = run_window(pt, q, {"%[act]": act, "%[n]": n})
                 want = pt
                 for _ in range(n):
                     want = [list(v) for v in _jac_dbl_model(*want)]
@@ -575,7 +645,7 @@ def test_doubling_asm_declares_its_registers_and_kernels_leave_room():
     kernel that inlines it is built for at most two waves per SIMD (the block owns registers up to v255)"""
     _, whole = _jac_lines()
     fns = re.findall(r"SSA_DEV \w+ (\w+)\(.*?asm volatile\(\n(.*?)\n        : (.*?)\);\n", whole, re.S)
-    assert [f[0] for f in fns] == ["jac_dbl_n_asm", "jac_madd_asm", "jac_window_asm"]
+    assert [f[0] for f in fns] == ["jac_dbl_n_asm", "jac_madd_asm", "jac_window_asm", "jac_madd_gather_asm"]
     for name, body, tail in fns:
         clob = set(re.findall(r'"(\w+)"', tail.split("\n        : ")[-1]))
         pinned = set()

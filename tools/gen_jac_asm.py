@@ -327,33 +327,62 @@ def build_dbl(tag=""):
     return gen
 
 
-def build_madd(tag=""):
+# First instruction of every statement.  The compiler keeps values in registers these statements clobber and reloads them from
+# scratch behind each statement; it waits for such a reload where the VALUE is next used -- not in front of an inline asm
+# that merely clobbers the register (measured: ssa_k_sign entered the gathering addition with four reloads in flight, which
+# then landed in the statement's temporaries: wrong signatures on ~7 % of the waves, different ones from run to run).  The
+# statements whose operands the compiler loads itself were shielded by its wait for those operands; the gathering ones are
+# not.  So: nothing of the compiler's may be in flight when a statement starts.
+ENTRY_WAIT = "s_waitcnt vmcnt(0)"
+Q_WAIT = "s_waitcnt vmcnt(2)"       # late_q: the statement's own six loads of (x2, y2) have landed; its two touches may be out
+
+
+def build_madd(tag="", late_q=False):
     """(X, Y, Z) += (x2, y2), the generic path of the mixed addition (7M + 4S as 8 products + 3 squares):
         Z1Z1 = Z^2   T = y2 Z   H = x2 Z1Z1 - X   R = T Z1Z1 - Y   HH = H^2   Z3 = Z H   HHH = HH H   V = X HH
         X3 = R^2 - HHH - 2V      Y3 = (V - X3) R + HHH (-Y)
     The exceptional inputs (Z == 0, (x2, y2) == (0, 0), H == 0) are NOT handled here: a necessary condition of each
     (first coefficient zero mod p) is tested before anything is written, and the block then leaves the point untouched
-    and reports 0 -- the caller runs the compiled, exact jac_madd for that wave.  Honest inputs never get there."""
+    and reports 0 -- the caller runs the compiled, exact jac_madd for that wave.  Honest inputs never get there.
+    late_q (the statement that gathers (x2, y2) itself, emit_madd_gather): everything that does not need the second
+    point comes first -- Z1Z1 = Z^2 and ZZZ = Z1Z1 Z, 57 products --, then the wait for the loads (Q_WAIT), then
+    H = x2 Z1Z1 - X and R = y2 ZZZ - Y: the same eight products and three squares, one more pre-scaled operand."""
     gen = Gen(n_slots=5, n_pb=17, n_pinned_in=12, tag=tag)
     S = gen.S
     x2, y2 = gen.IN[0:6], gen.IN[6:12]
     Z1Z1, T, H, R, HH = S[0], S[1], S[2], S[3], S[4]
     Z3, HHH, V, NY = S[0], S[1], S[4], S[2]
     f, w = gen.G, gen.TMP
-    # exceptional inputs, part 1 (G doubles as the flag word here; the guards below rewrite it afterwards)
-    gen.main += gen.zero_word(w, ZR[0])
-    gen.main += ["v_mov_b32 v%d, v%d" % (gen.MASK, w)]
-    gen.main += gen.zero_word(w, x2[0])
-    gen.main += ["v_min_u32 v%d, v%d, v%d" % (gen.MASK, gen.MASK, w), "v_cmp_eq_u32 vcc, 0, v%d" % gen.MASK, VCC_ACTIVE,
-                 "s_cbranch_vccnz L_bail_%="]
-    # 1. Z1Z1 = Z^2, T = y2 * Z
-    d, s, t, _ = pres(gen, ZR, 1, 1, 4)
-    gen.block(g6.sqr_terms(), sqr_regs(ZR, d, s, t), Z1Z1)
-    gen.block(g6.mul_terms(), mul_regs(y2, ZR, s), T)
-    # 2. H = x2 Z1Z1 - X, R = T Z1Z1 - Y
-    _, s, _, _ = pres(gen, Z1Z1, None, 1, None)
-    gen.block(g6.mul_terms(), mul_regs(x2, Z1Z1, s), H, extras=[(-1, 1, "x")], extra_regs={"x": XR})
-    gen.block(g6.mul_terms(), mul_regs(T, Z1Z1, s), R, extras=[(-1, 1, "x")], extra_regs={"x": YR})
+    if late_q:
+        gen.main += gen.zero_word(w, ZR[0])
+        gen.main += ["v_cmp_eq_u32 vcc, 0, v%d" % w, VCC_ACTIVE, "s_cbranch_vccnz L_bail_%="]
+        # 1. Z1Z1 = Z^2, ZZZ = Z1Z1 * Z (in T's slot)
+        d, s, t, _ = pres(gen, ZR, 1, 1, 4)
+        gen.block(g6.sqr_terms(), sqr_regs(ZR, d, s, t), Z1Z1)
+        gen.block(g6.mul_terms(), mul_regs(Z1Z1, ZR, s), T)
+        gen.main += [Q_WAIT]
+        gen.main += gen.zero_word(w, x2[0])
+        gen.main += ["v_cmp_eq_u32 vcc, 0, v%d" % w, VCC_ACTIVE, "s_cbranch_vccnz L_bail_%="]
+        # 2. H = x2 Z1Z1 - X, R = y2 ZZZ - Y
+        _, s, _, _ = pres(gen, Z1Z1, None, 1, None)
+        gen.block(g6.mul_terms(), mul_regs(x2, Z1Z1, s), H, extras=[(-1, 1, "x")], extra_regs={"x": XR})
+        _, s, _, _ = pres(gen, T, None, 1, None)
+        gen.block(g6.mul_terms(), mul_regs(y2, T, s), R, extras=[(-1, 1, "x")], extra_regs={"x": YR})
+    else:
+        # exceptional inputs, part 1 (G doubles as the flag word here; the guards below rewrite it afterwards)
+        gen.main += gen.zero_word(w, ZR[0])
+        gen.main += ["v_mov_b32 v%d, v%d" % (gen.MASK, w)]
+        gen.main += gen.zero_word(w, x2[0])
+        gen.main += ["v_min_u32 v%d, v%d, v%d" % (gen.MASK, gen.MASK, w), "v_cmp_eq_u32 vcc, 0, v%d" % gen.MASK, VCC_ACTIVE,
+                     "s_cbranch_vccnz L_bail_%="]
+        # 1. Z1Z1 = Z^2, T = y2 * Z
+        d, s, t, _ = pres(gen, ZR, 1, 1, 4)
+        gen.block(g6.sqr_terms(), sqr_regs(ZR, d, s, t), Z1Z1)
+        gen.block(g6.mul_terms(), mul_regs(y2, ZR, s), T)
+        # 2. H = x2 Z1Z1 - X, R = T Z1Z1 - Y
+        _, s, _, _ = pres(gen, Z1Z1, None, 1, None)
+        gen.block(g6.mul_terms(), mul_regs(x2, Z1Z1, s), H, extras=[(-1, 1, "x")], extra_regs={"x": XR})
+        gen.block(g6.mul_terms(), mul_regs(T, Z1Z1, s), R, extras=[(-1, 1, "x")], extra_regs={"x": YR})
     # exceptional inputs, part 2: H == 0 (P == +-Q)
     gen.main += gen.zero_word(w, H[0])
     gen.main += ["v_cmp_eq_u32 vcc, 0, v%d" % w, VCC_ACTIVE, "s_cbranch_vccnz L_bail_%="]
@@ -438,7 +467,7 @@ def asm_lines(out, body):
 
 def emit_dbl():
     gen = build_dbl()
-    pre = ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["s_mov_b32 s20, %[n]", "L_top_%=:"] + fair_read()
+    pre = [ENTRY_WAIT] + ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["s_mov_b32 s20, %[n]", "L_top_%=:"] + fair_read()
     post = fair_set("f") + ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%=", "s_branch L_end_%="]
     body = pre + gen.main + post + gen.cold + ["L_end_%=:"]
     used, n_valu, n_mad, n_nop = check_and_stats(gen, body, _pin_regs)
@@ -463,7 +492,7 @@ def emit_dbl():
 def emit_madd():
     gen = build_madd()
     pinned = _pin_regs | set(r for p in gen.IN for r in (p, p + 1))
-    pre = ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["v_mov_b32 %[ok], 1"]
+    pre = [ENTRY_WAIT] + ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["v_mov_b32 %[ok], 1"]
     post = ["s_branch L_end_%="]
     bail = ["L_bail_%=:", "v_mov_b32 %[ok], 0"]
     body = pre + gen.main + post + gen.cold + bail + ["L_end_%=:"]
@@ -492,15 +521,75 @@ def emit_madd():
     return out
 
 
+PF = 117         # the touches' landing register: outside every register the statements name
+KEEP = 38        # v[38:39]: outside every register the window / gather statements name
+
+
+def emit_madd_gather():
+    """the mixed addition that gathers its own second point and touches the NEXT one (comb tables: 96-byte entries at random
+    places of a table far larger than the caches -- 17.7 GB for G, 100 MB per key --, one addition after the other).  The
+    statement issues the six loads of (x2, y2) from `row` and, behind them, two one-word loads of the first and last word
+    of the entry at `next` (whatever lines it lies in are then on their way into the L2 while this addition runs); the
+    additions' own loads are awaited after the 57 products that do not need them (loads return in order: vmcnt(2)), the
+    touches at the end of the statement, long landed."""
+    gen = build_madd("g", late_q=True)
+    in_regs = set(r for p in gen.IN for r in (p, p + 1))
+    assert gen.IN == list(range(gen.IN[0], gen.IN[0] + 24, 2)) and gen.IN[0] % 4 == 0
+    pinned = _pin_regs | in_regs
+    loads = ["global_load_dwordx4 v[%d:%d], %%[row], off%s" % (gen.IN[0] + 4 * k, gen.IN[0] + 4 * k + 3, " offset:%d" % (16 * k) if k else "")
+             for k in range(6)]
+    loads += ["global_load_dword v%d, %%[next], off" % PF, "global_load_dword v%d, %%[next], off offset:92" % PF]
+    pre = [ENTRY_WAIT] + loads + ["v_mov_b32 v%d, 0" % r for r in gen.zero_regs] + ["v_mov_b32 %[ok], 1"]
+    post = ["s_branch L_end_%="]
+    bail = ["L_bail_%=:", "v_mov_b32 %[ok], 0"]
+    body = pre + gen.main + post + gen.cold + bail + ["L_end_%=:", "s_waitcnt vmcnt(0)"]
+    assert body.count(Q_WAIT) == 1
+    used, n_valu, n_mad, n_nop = check_and_stats(gen, [ln for ln in body if "%[" not in ln], pinned | {PF})
+    used = used | in_regs | {PF}
+    assert PF not in _pin_regs and PF not in set(gen.al.used)
+    out = ["// (X, Y, Z) += the point at row[0..11], gathered by the statement itself; `next`: the entry the NEXT addition will",
+           "// want (its first and last word are loaded and dropped: a prefetch).  Returns 0 with the point untouched when an",
+           "// exceptional input is possible: the caller then loads the point and runs jac_madd.",
+           "// %d VALU instructions (%d multiplies) + %d s_nop on the hot path." % (n_valu, n_mad, n_nop),
+           "// keep: as in jac_window_asm (the table's base, handed through in v[%d:%d])." % (KEEP, KEEP + 1),
+           "SSA_DEV u32 jac_madd_gather_asm(u64 (&X)[6], u64 (&Y)[6], u64 (&Z)[6], const u64 *row, const u64 *next, const u64 *&keep) {",
+           "    u32 ok;", "    asm volatile("]
+    asm_lines(out, body)
+    ops = ['[ok] "=&v"(ok)']
+    for nm, regs in (("X", XR), ("Y", YR), ("Z", ZR)):
+        for j in range(6):
+            ops.append('"+{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
+    assert KEEP not in used and KEEP + 1 not in used and KEEP not in pinned and KEEP + 1 not in pinned
+    ops.append('"+{v[%d:%d]}"(keep)' % (KEEP, KEEP + 1))
+    out.append("        : " + ",\n          ".join(ops))
+    out.append('        : [row] "v"(row), [next] "v"(next)')
+    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(26 if FAIR else 21)] + ['"vcc"', '"scc"', '"memory"']
+    out.append("        : " + ", ".join(clob) + ");")
+    out += ["    return ok;", "}"]
+    print("mixed addition with its gather: %d VALU (%d multiplies), %d s_nop; %d VGPRs + 36 pinned; %d cold-path lines"
+          % (n_valu, n_mad, n_nop, len(used), len(gen.cold)))
+    return out
+
+
+
+
 def emit_window():
     """n doublings, then the mixed addition on the lanes whose `act` word is non-zero (EXEC narrowed inside the
-    statement): one statement per ladder window, the point never leaves its registers in between"""
+    statement): one statement per ladder window, the point never leaves its registers in between.
+    Round 5: the statement GATHERS its own table entry.  It takes the lane's row address, issues the six 16-byte loads of
+    (x2, y2) as its first instructions and waits for them behind the doublings -- 13 000 instructions later --, where the
+    compiled loop waited for the whole HBM latency of a lane-private line in front of every window
+    (profiles/r05/gather_ab.txt).  The wait stands in front of the EXEC narrowing, on every path out of the statement: the
+    loaded registers are the statement's clobbers, the compiler may reuse them right behind it."""
     gd, gm = build_dbl("d"), build_madd("m")
     in_regs = set(r for p in gm.IN for r in (p, p + 1))
     assert not (set(gd.al.used) & in_regs)
+    assert gm.IN == list(range(gm.IN[0], gm.IN[0] + 24, 2)) and gm.IN[0] % 4 == 0      # x2, y2: 24 consecutive VGPRs
     pinned = _pin_regs | in_regs
-    pre = ["v_mov_b32 v%d, 0" % r for r in gd.zero_regs] + ["v_mov_b32 %[ok], 1", "s_mov_b32 s20, %[n]", "L_top_%=:"] + fair_read()
-    loop_end = fair_set("f") + ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%="]
+    loads = ["global_load_dwordx4 v[%d:%d], %%[row], off%s" % (gm.IN[0] + 4 * k, gm.IN[0] + 4 * k + 3, " offset:%d" % (16 * k) if k else "")
+             for k in range(6)]
+    pre = [ENTRY_WAIT] + loads + ["v_mov_b32 v%d, 0" % r for r in gd.zero_regs] + ["v_mov_b32 %[ok], 1", "s_mov_b32 s20, %[n]", "L_top_%=:"] + fair_read()
+    loop_end = fair_set("f") + ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 L_top_%=", "s_waitcnt vmcnt(0)"]
     narrow = ["v_cmp_ne_u32 vcc, 0, %[act]", "s_and_saveexec_b64 s[22:23], vcc", "s_cbranch_execz L_skip_%="]
     zero_m = ["v_mov_b32 v%d, 0" % r for r in gm.zero_regs if r not in gd.zero_regs]
     skip = ["L_skip_%=:", "s_mov_b64 exec, s[22:23]", "s_branch L_end_%="]
@@ -508,27 +597,30 @@ def emit_window():
     body = pre + gd.main + loop_end + narrow + zero_m + gm.main + skip + gd.cold + gm.cold + bail + ["L_end_%=:"]
     plain = [ln for ln in body if "%[" not in ln]
     used_d, nv_d, nm_d, nn_d = check_and_stats(gd, [ln for ln in plain], pinned | set(gm.al.used) | set(g6.POOL[:g6.N_FIXED + 4]))
-    used = used_d | set(gm.al.used)
+    used = used_d | set(gm.al.used) | in_regs
     out = ["// n doublings, then (X, Y, Z) += (x2, y2) on the lanes with act != 0: one ladder window as ONE statement.",
+           "// (x2, y2) = row[0..11]: the statement loads them itself, under the doublings (row: this lane's table entry).",
            "// Returns 0 when the addition met a possible exceptional input on some lane (the doublings are done, the addition",
            "// is not: the caller runs the compiled jac_madd on the lanes with act != 0).",
-           "SSA_DEV u32 jac_window_asm(u64 (&X)[6], u64 (&Y)[6], u64 (&Z)[6], const u64 (&x2)[6], const u64 (&y2)[6], u32 act, u32 n) {",
+           "// keep: a pointer the caller wants to find in a REGISTER behind the statement (the ladder's table base: the",
+           "// compiler otherwise parks it in scratch and waits for the reload in front of every window); pinned to",
+           "// v[%d:%d], which the statement does not touch." % (KEEP, KEEP + 1),
+           "SSA_DEV u32 jac_window_asm(u64 (&X)[6], u64 (&Y)[6], u64 (&Z)[6], const u64 *row, u32 act, u32 n, const u64 *&keep) {",
            "    u32 ok;", "    asm volatile("]
     asm_lines(out, body)
     ops = ['[ok] "=&v"(ok)']
     for nm, regs in (("X", XR), ("Y", YR), ("Z", ZR)):
         for j in range(6):
             ops.append('"+{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
+    assert KEEP not in used and KEEP + 1 not in used and KEEP not in pinned and KEEP + 1 not in pinned
+    ops.append('"+{v[%d:%d]}"(keep)' % (KEEP, KEEP + 1))
     out.append("        : " + ",\n          ".join(ops))
-    ins = ['[act] "v"(act)', '[n] "s"(__builtin_amdgcn_readfirstlane(n))']
-    for nm, regs in (("x2", gm.IN[0:6]), ("y2", gm.IN[6:12])):
-        for j in range(6):
-            ins.append('"{v[%d:%d]}"(%s[%d])' % (regs[j], regs[j] + 1, nm, j))
+    ins = ['[act] "v"(act)', '[n] "s"(__builtin_amdgcn_readfirstlane(n))', '[row] "v"(row)']
     out.append("        : " + ",\n          ".join(ins))
-    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(26 if FAIR else 24)] + ['"vcc"', '"scc"']
+    clob = ['"v%d"' % r for r in sorted(used)] + ['"s%d"' % i for i in range(26 if FAIR else 24)] + ['"vcc"', '"scc"', '"memory"']
     out.append("        : " + ", ".join(clob) + ");")
     out += ["    return ok;", "}"]
-    print("window: %d fixed VGPRs + 60 pinned" % len(used))
+    print("window: %d fixed VGPRs + 36 pinned" % len(used))
     return out
 
 
@@ -538,7 +630,7 @@ OUT_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 def generate():
     """the text of jac_asm.inc (the freshness test compares it with the committed file without writing anything)"""
     out = ["// generated by tools/gen_jac_asm.py -- do not edit (see that file for the design notes)"] + emit_dbl() + [""] + emit_madd() \
-        + [""] + emit_window()
+        + [""] + emit_window() + [""] + emit_madd_gather()
     return "\n".join(out) + "\n"
 
 
