@@ -341,3 +341,27 @@ def test_end_game_pieces_equal_whole_lanes(engine, oracle, pieces, gens, uniform
         assert (a == b).all()
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------- the statements that gather their own operands
+def test_signer_and_verifier_are_deterministic_at_full_occupancy(engine):
+    """2^19 keygen + sign twice from the same inputs: the same bytes, and every signature verifies under both kernel
+    families' large-batch path.  The generated statements of jac_asm.inc gather their own table entries since round 5; the
+    compiler does not wait for its scratch reloads into registers such a statement only clobbers, and before every statement
+    started with its own wait the signer's second comb ran with reloads in flight: wrong R on some waves, different ones
+    from run to run (profiles/r05/gather_ab.txt).  Only a full machine shows it: the reloads must be slow enough."""
+    n = 1 << 19
+    rng = np.random.default_rng(77)
+    sks = rng.integers(1, 255, size=(n, 32), dtype=np.uint8)
+    sks[:, 31] &= 0x3F
+    nonces = rng.integers(1, 255, size=(n, 32), dtype=np.uint8)
+    nonces[:, 31] &= 0x3F
+    msgs = rng.integers(0, 256, size=(n, 80), dtype=np.uint8)
+    pks, sigs = engine.keygen_sign_many(sks, nonces, msgs)
+    pks2, sigs2 = engine.keygen_sign_many(sks, nonces, msgs)
+    assert (pks == pks2).all() and (sigs == sigs2).all()
+    for torsion in (False, True):
+        st, nf = engine.verify_many(sigs, pks, msgs, check_torsion=torsion, mode="lane")
+        assert nf == 0 and not st.any()
+    st2, nf2 = engine.verify_many(sigs, pks, msgs, mode="lane", sig_flag_byte=True)
+    assert nf2 == 0 and not st2.any()
