@@ -1408,6 +1408,10 @@ extern "C" int ssa_bench_fpmul(ssa_ctx *ctx, int variant, double *fpmul_per_s) {
 }
 
 #ifdef SSA_WAVE_TIMES
+extern "C" int ssa_debug_phase_times(unsigned long long *out, size_t n_waves) {
+    if (n_waves > ssa::SSA_WAVE_TIMES_MAX) n_waves = ssa::SSA_WAVE_TIMES_MAX;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ssa::g_phase_times), 4 * n_waves * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 // diagnostic build only: (start, end, hardware id) of every wave of the LAST ssa_k_verify launch, wall_clock64 ticks (100 MHz)
 extern "C" int ssa_debug_wave_times(unsigned long long *out, size_t n_waves) {
     if (n_waves > ssa::SSA_WAVE_TIMES_MAX) n_waves = ssa::SSA_WAVE_TIMES_MAX;

@@ -569,6 +569,12 @@ constexpr u32 VF_CHECK_TORSION = 1u, VF_SIG_FLAG_BYTE = 8u;
 #ifdef SSA_WAVE_TIMES
 constexpr size_t SSA_WAVE_TIMES_MAX = 1u << 16;
 __device__ unsigned long long g_wave_times[3 * SSA_WAVE_TIMES_MAX];
+// ... and where an ORDINARY wave's time goes (tools/wave_times.py --phases): start, table built, ladder done, end
+__device__ unsigned long long g_phase_times[4 * SSA_WAVE_TIMES_MAX];
+#define SSA_PHASE_MARK(k) do { if (!in_piece && lane == 0 && (size_t)blockIdx.x * 4u + (threadIdx.x >> 6) < SSA_WAVE_TIMES_MAX) \
+    g_phase_times[4 * ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6)) + (k)] = wall_clock64(); } while (0)
+#else
+#define SSA_PHASE_MARK(k) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -722,6 +728,7 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
         if (!ok) status = ST_MALFORMED;
         else build_ptab(tab, P, inf);
     }
+    SSA_PHASE_MARK(1);
     // pass 0 (only with SSA_FLAG_CHECK_TORSION): [q]P == O, is_torsion_free, :182-184 -- the offline schedule of the
     // constant q; pass 1: [h]P.  One rolled loop (ladder_steps) so that the ladder body exists once in the code.
     if (in && status == ST_OK) {
@@ -751,6 +758,7 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
             }
         }
     }
+    SSA_PHASE_MARK(2);
     if (runs_last) {
         if (in) {
             if (status == ST_OK) {
@@ -803,9 +811,11 @@ ssa_k_verify(const u8 *__restrict__ sigs, const u8 *__restrict__ pks,
         }
     }
 #ifdef SSA_WAVE_TIMES
+    SSA_PHASE_MARK(3);
     if (lane == 0) {
         const size_t w = (size_t)blockIdx.x * (blockDim.x / 64u) + (threadIdx.x >> 6);
         if (w < SSA_WAVE_TIMES_MAX) {
+            if (!in_piece) g_phase_times[4 * w] = wt0;
             g_wave_times[3 * w] = wt0;
             g_wave_times[3 * w + 1] = wall_clock64();
             g_wave_times[3 * w + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |

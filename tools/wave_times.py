@@ -26,6 +26,20 @@ def main():
                                check_torsion=False, sig_flag_byte=True)
         eng.sync()
     lib = C.CDLL(os.environ["SSA_LIB"])
+    if "--phases" in sys.argv:
+        # where an ordinary wave's time goes, against where its instructions are (tail_plan's counts: table 57 k,
+        # 50 windows of 16.9 k, comb + comparison 45 k)
+        ph = np.zeros((1 << 16, 4), dtype=np.uint64)
+        assert lib.ssa_debug_phase_times(ph.ctypes.data_as(C.c_void_p), C.c_size_t(1 << 16)) == 0
+        ph = ph[(ph[:, 0] != 0) & (ph[:, 3] != 0) & (ph[:, 3] + np.uint64(20_000_000) >= ph[:, 3].max())].astype(np.float64) / 100.0
+        d = np.diff(ph, axis=1)
+        tot = d.sum(axis=1)
+        share = (57.0, 847.4, 45.0)
+        print("%d ordinary waves, mean life %.1f us" % (len(ph), tot.mean()))
+        for k, nm in enumerate(("start -> table built", "ladder (50 windows)", "comb + comparison")):
+            print("  %-22s mean %7.1f us = %5.2f %% of the wave's life; %5.2f %% of its instructions; us per 1000 instructions %.3f"
+                  % (nm, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean(), 100 * share[k] / sum(share), d[:, k].mean() / share[k]))
+        return
     cap = 1 << 16
     raw = np.zeros((cap, 3), dtype=np.uint64)
     assert lib.ssa_debug_wave_times(raw.ctypes.data_as(C.c_void_p), C.c_size_t(cap)) == 0
