@@ -206,6 +206,12 @@ REDUCE_STEPS = [
 ]
 
 
+# First instruction of every block (as in tools/gen_jac_asm.py, where the reason was found): the compiler reloads values it
+# keeps in registers a block clobbers from scratch behind the block and does not wait for such a reload in front of the
+# NEXT block that merely clobbers the register; a reload still in flight would land in the block's accumulators.
+ENTRY_WAIT = "s_waitcnt vmcnt(0)"
+
+
 def reduce3(accs, outs, label):
     """outs[j] = (lo, hi) destination of chain j's result; label: unique name stem of this group's cold path.
     Returns (hot lines, cold lines): the hot lines end in a branch to the cold path (taken ~once in 10^8 groups) and the
@@ -279,7 +285,7 @@ def sqr_terms():
 def emit(name, terms, inputs, doc, extras=()):
     """extras: fused linear terms (sign, small constant, operand prefix); their operand arrays are appended to inputs"""
     accs = [Acc(j) for j in range(6)]
-    lines = []
+    lines = [ENTRY_WAIT]
     cold = []
     bias, bias_setup = extras_bias(extras)
     lines += bias_setup
@@ -355,7 +361,7 @@ def f3_sqr_terms():
 
 def emit3(name, terms, inputs, doc):
     accs = [Acc(j) for j in range(3)]
-    lines = []
+    lines = [ENTRY_WAIT]
     for k in range(3):
         t = terms[k]
         lines += init2(accs[k], t[0][0], t[0][1], t[1][0], t[1][1], None)
@@ -434,7 +440,7 @@ def pad_wait_states(lines, gap=3):
 
 def emit_acc3(name, doc):
     acc = Acc(0)
-    lines = init2(acc, "x0", "y0", "x1", "y1", None) + mac(acc, "x2", "y2")
+    lines = [ENTRY_WAIT] + init2(acc, "x0", "y0", "x1", "y1", None) + mac(acc, "x2", "y2")
     m = {"c0p": acc.pair(0), "c0l": acc.lo(0), "c0h": acc.hi(0), "c1l": acc.lo(1), "c1h": acc.hi(1), "c2l": acc.lo(2),
          "c2h": acc.hi(2), "k0": acc.kk(0), "k1": acc.kk(1), "k2": acc.kk(2), "A": "s[0:1]", "B": "s[2:3]", "T": "s[14:15]",
          "outl": "%[rl]", "outh": "%[rh]"}

@@ -263,10 +263,10 @@ def emit_program(name, prog, doc, nch=None):
              "// straight into them); st collects the lanes (bit per lane) where a reduction met its rare borrow: their values are",
              "// then WRONG and the caller recomputes them from its inputs with the compiled exact code (rescue.hpp)",
              "SSA_DEV void %s(%s, u64 &st) {" % (name, ", ".join("u64 &" + a for a in args)), "    asm volatile("]
-    body = []
+    body = ["s_waitcnt vmcnt(0)"]       # nothing of the compiler's in flight into the block's registers (tools/gen_jac_asm.py)
     for g in gs:
         body += zero_inits(g)
-    counts = {"valu": len(body), "nop": 0}
+    counts = {"valu": len(body) - 1, "nop": 0}
     for kind, v, src, dst in rename(prog):
         chains = []
         for c, g in enumerate(gs):
