@@ -76,8 +76,10 @@ extern "C" {
                                              with n, for device-pointer AND host-buffer entry points: workspaces and
                                              staging are sized for slices of 2^20 lanes (4.4 GB of tables + 0.3 GB of
                                              staging per slice in flight, at most two; SSA_LANE_SLICE), resp. 2^23
-                                             signatures of the MSM form (SSA_MSM_SLICE); only the slice in flight is
-                                             pinned */
+                                             signatures of the MSM form (SSA_MSM_SLICE).  The host-buffer entry points
+                                             copy the caller's bytes through page-locked bounce buffers of the library's,
+                                             the size of one slice's inputs (0.3 GB, resp. 2.2 GB for a full MSM slice);
+                                             the caller's memory is never registered with the runtime */
 #define SSA_FLAG_FORCE_LANE 2u    /* always the throughput kernels (one signature per lane) */
 #define SSA_FLAG_FORCE_COOP 4u    /* always the low-latency kernel (one wave per signature) */
 #define SSA_FLAG_CHECK_TORSION 1u /* Signature::verify semantics (src/signature.rs:182-184);

@@ -568,8 +568,8 @@ class Engine:
         for _ in range(reps):
             verdict = self.verify_batch_msm(hs, hp, hm)
         dt_msm = (time.perf_counter() - t0) / reps
-        return {"entry_point": "ssa_verify_many (host buffers in pageable memory, pinned in place per call, "
-                               "uploads in chunks overlapped with the hash kernel)",
+        return {"entry_point": "ssa_verify_many (host buffers in pageable memory, copied through the library's page-locked "
+                               "bounce buffers, uploads in chunks overlapped with the hash kernel)",
                 "ms_per_batch": dt * 1e3, "verifications_per_sec": n / dt, "rejected": int(nf),
                 "verify_batch_msm_ms_per_batch": dt_msm * 1e3, "verify_batch_msm_signatures_per_sec": n / dt_msm,
                 "verify_batch_msm_verdict": int(verdict)}

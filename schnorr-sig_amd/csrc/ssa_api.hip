@@ -357,6 +357,7 @@ extern "C" void ssa_ctx_destroy(ssa_ctx *ctx) {
                       &ctx->msm_partials, &ctx->msm_flags, &ctx->st_coeffs, &ctx->msm_cnt, &ctx->msm_cnt2,
                       &ctx->msm_ids, &ctx->msm_ids2, &ctx->msm_comb_pts, &ctx->msm_comb_lins, &ctx->msm_slice_recs, &ctx->msm_sbuf, &ctx->tail_done, &ctx->tail_park, &ctx->ctab, &ctx->sg_sigs, &ctx->sg_pks})
         b->release();
+    for (HostBuf *b : {&ctx->pin_in, &ctx->pin_coeffs, &ctx->pin_out}) b->release();
     if (ctx->d_params) (void)hipFree(ctx->d_params);
     gtab_release(ctx->gtab_share);
     ctx->gtab_share = nullptr;
@@ -760,7 +761,7 @@ static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_
                                  size_t n, uint32_t flags, uint8_t *status_out, uint64_t *n_fail_out, bool *used) {
     PipelinedInputs pin;      // its destructor drains the side streams on every error return below
     *used = false;
-    if (!pin.r_status.pin(status_out, n)) return 0;
+    if (ctx->pin_out.reserve(n)) return 0;          // (no page-locked memory: the staged path)
     if (int rc = pipelined_upload_hash(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, pin, used)) return rc;
     if (!*used) return 0;
     const size_t slice = ctx->lane_slice < n ? ctx->lane_slice : n;
@@ -773,11 +774,12 @@ static int verify_many_pipelined(ssa_ctx *ctx, const uint8_t *sigs, const uint8_
     if (int rc = verify_slices(ctx, pin.s.sigs, pin.s.pks, pin.s.inf, (const u64 *)ctx->ws_h.p, n, flags,
                                (u8 *)ctx->st_status.p, d_fail))
         return rc;
-    HIP_TRY(hipMemcpyAsync(status_out, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->st_status.p, n, hipMemcpyDeviceToHost, ctx->stream));
     unsigned long long nf = 0;
     HIP_TRY(hipMemcpyAsync(&nf, d_fail, sizeof nf, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     pin.done();
+    std::memcpy(status_out, ctx->pin_out.p, n);
     if (n_fail_out) *n_fail_out = nf;
     return 0;
 }

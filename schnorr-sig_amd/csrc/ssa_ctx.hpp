@@ -53,6 +53,32 @@ struct DevBuf {
     }
 };
 
+// page-locked HOST memory owned by the library (hipHostMalloc): what the DMA engines read and write in the host-buffer entry
+// points.  The caller's memory itself is never registered with the runtime (see pipelined_upload_hash).
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return SSA_ERR_HIP;
+        }
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct TimedLaunch {
     hipEvent_t start, stop;
 };
@@ -116,6 +142,9 @@ struct ssa_ctx {
     unsigned tail_min_main = 0;   // SSA_TAIL_MIN_MAIN: generations of ordinary workgroups a launch must have beside its tail
     unsigned tail_waves_override = 0;   // SSA_TAIL_WAVES: the tests' small "generation" (the end game on batches of thousands)
     DevBuf tail_done, tail_park;  // per tail group: finished pieces; parked accumulators + status (152 B per lane)
+    // page-locked bounce buffers of the host-buffer entry points: one slice of inputs (257 B + message per lane), the
+    // caller's coefficients of the MSM form, one slice of statuses
+    HostBuf pin_in, pin_coeffs, pin_out;
     std::map<std::string, std::vector<TimedLaunch>> timed;
     std::vector<struct ssa_keyset *> keysets;   // live key sets of this context (orphaned, not leaked, by ssa_ctx_destroy)
 };
@@ -197,47 +226,55 @@ static inline int stage_msgs(ssa_ctx *ctx, const uint8_t *msgs, const uint64_t *
 int ssa_internal_hash_chunk(ssa_ctx *ctx, hipStream_t hs, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_msgs,
                             const uint64_t *d_off, size_t msg_stride, size_t msg_len, size_t cnt, uint64_t *d_h);
 
-// Caller memory pinned in place for the duration of one call (hipHostRegister): the DMA engines then read it
-// directly and asynchronously -- an upload from pageable memory is staged by the runtime and does not overlap the
-// kernels (measured: DESIGN.md).  Never kept across calls: the caller may free or remap the range.
-struct PinnedRange {
-    void *p = nullptr;
-    bool on = false;
-    bool pin(const void *ptr, size_t bytes) {
-        if (!ptr || bytes == 0) return true;
-        const hipError_t err = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault);
-        if (err != hipSuccess) {
-            (void)hipGetLastError();
-            if (ssa_debug_enabled())
-                std::fprintf(stderr, "[schnorr_sig_amd] hipHostRegister(%p, %zu) failed: %s -- staged copy instead\n", ptr, bytes,
-                             hipGetErrorString(err));
-            return false;
-        }
-        p = const_cast<void *>(ptr);
-        on = true;
-        return true;
-    }
-    ~PinnedRange() {
-        if (on) (void)hipHostUnregister(p);
-    }
-};
+// Host-buffer uploads go through page-locked memory of the LIBRARY's (ctx->pin_in): the caller's bytes are copied into it
+// by host threads, chunk by chunk, and the DMA engines read it asynchronously, under the kernels of the chunk before.
+// Rounds 3-5 registered the CALLER's memory with the runtime for the duration of a call instead (hipHostRegister: no host
+// copy, 29 M verifications/s).  That is not safe: for buffers that live in the process heap -- where glibc puts even
+// megabyte arrays once its mmap threshold has grown, and where a range shares its first and last page with its neighbours --
+// a later ordinary copy out of such memory faulted on the GPU side (`Memory access fault` on a page-aligned heap address;
+// tools/soak_large.py found it within ten iterations, never with the in-place registration off, never with the arrays in
+// their own mappings).  Whatever the runtime keeps of a registration, a library has no business changing the mapping state
+// of memory it does not own.
 struct PipelinedInputs {
-    // every caller range that a queued copy may still read or write is pinned HERE, so that the destructor below can
-    // drain the streams before any of them is unregistered (members are destroyed after the destructor body has run)
-    PinnedRange r_sigs, r_pks, r_msgs, r_inf, r_off, r_coeffs, r_status;
     StagedInputs s;     // device copies (context staging buffers)
     ssa_ctx *armed = nullptr;   // set with the first enqueue; cleared by done() once the call has synchronised
     void done() { armed = nullptr; }
     ~PipelinedInputs() {
-        // an error return after the first enqueue: copies out of (into) the caller's memory and hash launches that
-        // write ctx->ws_h may still be in flight -- wait for them before the ranges are unpinned and the caller
-        // gets its buffers back
+        // an error return after the first enqueue: copies out of the bounce buffers and hash launches that write
+        // ctx->ws_h may still be in flight -- wait for them before the next call reuses the buffers
         if (!armed) return;
         (void)hipStreamSynchronize(armed->copy_stream);
         for (auto &hs : armed->hash_stream) (void)hipStreamSynchronize(hs);
         (void)hipStreamSynchronize(armed->stream);
     }
 };
+
+// caller memory -> page-locked memory on up to SSA_COPY_THREADS (default 8) host threads (one thread moves ~10 GB/s; a
+// 2^20-signature slice is 270 MB and its upload must not take as long as its kernels)
+static inline size_t host_copy_threads() {
+    static const size_t t = [] {
+        const char *e = std::getenv("SSA_COPY_THREADS");
+        const long v = e ? std::atol(e) : 8;
+        return (size_t)(v < 1 ? 1 : v > 32 ? 32 : v);
+    }();
+    return t;
+}
+static inline void host_copy(void *dst, const void *src, size_t bytes) {
+    constexpr size_t PIECE = 4u << 20;
+    if (bytes <= 2 * PIECE || host_copy_threads() == 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t parts = bytes / PIECE < host_copy_threads() ? bytes / PIECE : host_copy_threads();
+    const size_t per = (bytes / parts + 63) & ~(size_t)63;
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < parts; t++) {
+        const size_t lo = t * per, hi = t + 1 == parts ? bytes : (t + 1) * per;
+        th.emplace_back([=] { std::memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, per < bytes ? per : bytes);
+    for (auto &x : th) x.join();
+}
 
 // debug hook of the error-path tests (ssa_debug_fault_after_chunk): the next pipelined upload fails (SSA_ERR_HIP) after
 // chunk k has been enqueued.  One shot, armed through the ABI on this context only: no environment is read per call.
@@ -264,9 +301,12 @@ static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const
     if (msg_off)
         for (size_t i = 0; i < n; i++)
             if (msg_off[i + 1] < msg_off[i] || msg_off[i + 1] - msg_off[i] > 0xffffffffull) return SSA_ERR_ARG;
-    if (!pin.r_sigs.pin(sigs, n * 81) || !pin.r_pks.pin(pks, n * 96) || !pin.r_msgs.pin(msgs, mb) ||
-        !pin.r_inf.pin(pk_inf, n) || !pin.r_off.pin(msg_off, msg_off ? (n + 1) * sizeof(uint64_t) : 0))
-        return 0;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_pks = al(n * 81), o_msgs = o_pks + al(n * 96), o_inf = o_msgs + al(mb),
+                 o_off = o_inf + al(pk_inf ? n : 0), total = o_off + al(msg_off ? (n + 1) * sizeof(uint64_t) : 0);
+    if (ctx->pin_in.reserve(total)) return 0;      // no page-locked memory to be had: the staged path
+    u8 *h_sigs = (u8 *)ctx->pin_in.p, *h_pks = h_sigs + o_pks, *h_msgs = h_sigs + o_msgs, *h_inf = h_sigs + o_inf,
+       *h_off = h_sigs + o_off;
     *used = true;
     if (ctx->st_sigs.reserve(n * 81) || ctx->st_pks.reserve(n * 96) || ctx->st_msgs.reserve(mb + 16) ||
         ctx->ws_h.reserve(n * 4 * sizeof(u64)) || (msg_off && ctx->st_off.reserve((n + 1) * sizeof(uint64_t))) ||
@@ -279,11 +319,13 @@ static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const
     const int fault_chunk = pipeline_fault_chunk(ctx);
     const u64 *d_off = nullptr;
     if (msg_off) {
-        HIP_TRY(hipMemcpyAsync(ctx->st_off.p, msg_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy_stream));
+        host_copy(h_off, msg_off, (n + 1) * sizeof(uint64_t));
+        HIP_TRY(hipMemcpyAsync(ctx->st_off.p, h_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy_stream));
         d_off = (const u64 *)ctx->st_off.p;
     }
     if (pk_inf) {
-        HIP_TRY(hipMemcpyAsync(ctx->st_inf.p, pk_inf, n, hipMemcpyHostToDevice, ctx->copy_stream));
+        host_copy(h_inf, pk_inf, n);
+        HIP_TRY(hipMemcpyAsync(ctx->st_inf.p, h_inf, n, hipMemcpyHostToDevice, ctx->copy_stream));
         pin.s.inf = (const u8 *)ctx->st_inf.p;
     }
     const unsigned chunks = ctx->pipeline_chunks;
@@ -291,12 +333,17 @@ static inline int pipelined_upload_hash(ssa_ctx *ctx, const uint8_t *sigs, const
     for (unsigned c = 0; c < chunks; c++) {
         const size_t lo = n * c / chunks, hi = n * (c + 1) / chunks, cnt = hi - lo;
         if (cnt == 0) continue;
-        HIP_TRY(hipMemcpyAsync(d_sigs + 81 * lo, sigs + 81 * lo, cnt * 81, hipMemcpyHostToDevice, ctx->copy_stream));
-        HIP_TRY(hipMemcpyAsync(d_pks + 96 * lo, pks + 96 * lo, cnt * 96, hipMemcpyHostToDevice, ctx->copy_stream));
+        // (the host copies of chunk c run while the DMA engines and the hash kernels work on chunk c - 1)
+        host_copy(h_sigs + 81 * lo, sigs + 81 * lo, cnt * 81);
+        HIP_TRY(hipMemcpyAsync(d_sigs + 81 * lo, h_sigs + 81 * lo, cnt * 81, hipMemcpyHostToDevice, ctx->copy_stream));
+        host_copy(h_pks + 96 * lo, pks + 96 * lo, cnt * 96);
+        HIP_TRY(hipMemcpyAsync(d_pks + 96 * lo, h_pks + 96 * lo, cnt * 96, hipMemcpyHostToDevice, ctx->copy_stream));
         const size_t m_lo = msg_off ? (size_t)msg_off[lo] : lo * msg_stride;
         const size_t m_hi = msg_off ? (size_t)msg_off[hi] : (hi == n ? mb : hi * msg_stride);
-        if (m_hi > m_lo)
-            HIP_TRY(hipMemcpyAsync(d_msgs + m_lo, msgs + m_lo, m_hi - m_lo, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (m_hi > m_lo) {
+            host_copy(h_msgs + m_lo, msgs + m_lo, m_hi - m_lo);
+            HIP_TRY(hipMemcpyAsync(d_msgs + m_lo, h_msgs + m_lo, m_hi - m_lo, hipMemcpyHostToDevice, ctx->copy_stream));
+        }
         HIP_TRY(hipEventRecord(ctx->copy_done[c], ctx->copy_stream));
         hipStream_t hs = ctx->hash_stream[c & 1u];
         HIP_TRY(hipStreamWaitEvent(hs, ctx->copy_done[c], 0));

@@ -1418,7 +1418,7 @@ static int msm_host_one(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, c
         // large batch: uploads pinned in place and chunked, the hashes (62 % of this form) run behind them
         PipelinedInputs pin;      // its destructor drains the side streams on every error return below
         bool used = false;
-        if (pin.r_coeffs.pin(coeffs, coeffs ? n * 32 : 0)) {
+        if (!coeffs || ctx->pin_coeffs.reserve(n * 32) == 0) {
             if (coeffs && ctx->st_coeffs.reserve(n * 32)) return SSA_ERR_HIP;
             if (int rc = pipelined_upload_hash(ctx, sigs, pks, pk_inf, msgs, msg_off, msg_stride, msg_len, n, pin, &used))
                 return rc;
@@ -1426,7 +1426,8 @@ static int msm_host_one(ssa_ctx *ctx, const uint8_t *sigs, const uint8_t *pks, c
                 const void *pc = nullptr;
                 if (coeffs) {
                     // behind the chunk copies on the copy stream; ctx->stream waits for this copy explicitly
-                    HIP_TRY(hipMemcpyAsync(ctx->st_coeffs.p, coeffs, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+                    host_copy(ctx->pin_coeffs.p, coeffs, n * 32);
+                    HIP_TRY(hipMemcpyAsync(ctx->st_coeffs.p, ctx->pin_coeffs.p, n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
                     HIP_TRY(hipEventRecord(ctx->pipe_start, ctx->copy_stream));
                     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->pipe_start, 0));
                     pc = ctx->st_coeffs.p;
