@@ -8,7 +8,9 @@ Per iteration:
     that expectation under the three semantics, device-pointer path through the host wrapper);
   * a random sample of 1536 lanes (all corrupted ones of the sample included) against the CPU oracle;
   * the MSM-form verdict of the corrupted batch (must reject) and of the honest one (must accept);
-  * every fourth iteration: the same signatures through a keyed context (64 signers) -- ladder tables and per-key combs.
+  * every fourth iteration: the same signatures through a keyed context (64 signers) -- ladder tables and per-key combs;
+    every fifth: the messages as one flat buffer with an offsets table; every seventh: a batch of more than one slice
+    (up to 2.5 * 2^20 signatures: bounded staging, two host threads, the twin context).
     python tools/soak_large.py [seconds]"""
 import os
 import sys
@@ -48,6 +50,8 @@ def check(cond, what):
 while time.time() - t0 < budget:
     rng = np.random.default_rng(0x50A4 + 7919 * it)
     n = int(rng.integers(1 << 17, (1 << 20) + 1))
+    if it % 7 == 6:
+        n = int(rng.integers((1 << 20) + 1, 5 << 19))          # more than one slice: the two-thread host path, the twin context
     mlen = int(rng.choice([80, 80, 32, 77, 160]))
     sks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); sks[:, 31] &= 0x3F; sks[:, 0] |= 1
     nonces = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); nonces[:, 31] &= 0x3F; nonces[:, 0] |= 1
@@ -90,6 +94,15 @@ while time.time() - t0 < budget:
     check(eng.verify_batch_msm(sigs, pks, msgs) == 2, "MSM form accepted the corrupted batch")
     trace("MSM form, honest")
     check(eng.verify_batch_msm(honest_sigs, honest_pks, honest_msgs) == 0, "MSM form rejected the honest batch")
+    if it % 5 == 4:
+        # the same corrupted batch as a flat message buffer with an offsets table (the reference's &[&[u8]]): same statuses
+        trace("offsets form")
+        off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(mlen))
+        st, nf = eng.verify_many(sigs, pks, msgs.reshape(-1), offsets=off, check_torsion=True, mode="lane")
+        want = np.zeros(n, dtype=np.uint8)
+        want[bad[kinds <= 3]] = 2
+        want[bad[kinds == 4]] = 1
+        check(nf == int((want != 0).sum()) and (st == want).all(), "offsets form differs from the construction")
     if it % 4 == 0:
         # 64 signers sign everything (their keys: the first 64 secret keys): key set with ladder tables, then with per-key combs
         ks = 64
