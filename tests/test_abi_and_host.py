@@ -147,3 +147,16 @@ def test_blob_from_upstream_round_trips_the_default_blob():
         bad = dict(spec)
         bad["generator"] = {"x": [2**64 - 1] + [0] * 5, "y": [0] * 6}
         bfu.build_blob(bad)
+
+
+def test_library_never_registers_caller_memory():
+    """The host-buffer entry points copy the caller's bytes into page-locked memory of the library's own; they must not
+    change the mapping state of memory they do not own.  Rounds 3-5 registered the caller's arrays in place
+    (hipHostRegister) for the duration of a call: with the arrays in the process heap a later plain copy faulted on the GPU
+    side (tools/soak_large.py).  The library must not even import the symbols."""
+    import subprocess
+    import schnorr_sig_amd as ssa
+    out = subprocess.run(["nm", "-D", "--undefined-only", ssa.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    imported = {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
+    assert "hipHostMalloc" in imported and "hipMemcpyAsync" in imported          # (the listing is what it should be)
+    assert not ({"hipHostRegister", "hipHostUnregister"} & imported)
