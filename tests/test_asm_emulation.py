@@ -712,3 +712,21 @@ def test_order_q_schedule_is_q():
     assert gaps[0] == 0 and 1 <= digits[0] <= 16 and all(1 <= g <= 64 for g in gaps[1:])
     assert all(d % 2 and abs(d) <= 15 for d in digits)
     assert n == 44 and sum(gaps) == 255                 # width-5 NAF: 43 additions, 255 doublings
+
+
+def test_every_generated_block_waits_for_the_compilers_loads_first():
+    """Every asm block of the three generated files starts with s_waitcnt vmcnt(0).  The blocks name their registers
+    themselves (clobber lists): the compiler keeps values in such registers between blocks, reloads them from scratch behind
+    a block, and does NOT wait for such a reload in front of the next block that merely clobbers the register -- a reload
+    still in flight lands in the block's temporaries (round 5: wrong signatures from ssa_k_sign on ~7 % of the waves,
+    profiles/r05/gather_ab.txt).  The three small statements of fp.hpp take compiler-allocated operands only and are not
+    concerned."""
+    csrc = os.path.dirname(INC)
+    n_blocks = 0
+    for name in ("fp6_asm.inc", "fp_chain_asm.inc", "jac_asm.inc"):
+        txt = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r"asm(?: volatile)?\(\n\s*\"([^\"]*)\"", txt):
+            n_blocks += 1
+            first = m.group(1).replace("\\n\\t", "").strip()
+            assert first == "s_waitcnt vmcnt(0)", (name, first)
+    assert n_blocks >= 20
